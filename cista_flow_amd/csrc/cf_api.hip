@@ -1,0 +1,899 @@
+// cf_api.hip -- C ABI + layer graphs of the CISTA-Flow hot path (see include/cistaflow.h).
+//
+// The graphs below restate, layer by layer, what the reference's nn.Modules compute:
+//   CistaLSTCNet          e2v/e2v_model.py:10-98, e2v/base_layers.py:21-227
+//   DCEIFlow              DCEIFlow/DCEIFlow.py:32-44,143-227,295-299
+//   BasicEncoder          DCEIFlow/core/backbone/raft_encoder.py:6-59,125-203
+//   update block          DCEIFlow/core/decoder/with_event_updater.py:6-14,35-67,90-112,156-171
+//   CorrBlock             DCEIFlow/core/corr/raft_corr.py:15-65
+//   wrapper (a5)          e2v/e2v_model.py:144-196
+#include "../../include/cistaflow.h"
+#include "cf_kernels.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace cf {
+long inorm_partial_doubles(int B, int HW, int C);
+}
+
+using namespace cf;
+
+static thread_local std::string g_create_error;
+
+namespace {
+
+struct RawWeight {
+    const float* ptr;
+    std::vector<int64_t> shape;
+    long numel() const {
+        long n = 1;
+        for (auto d : shape) n *= d;
+        return n;
+    }
+};
+
+struct PackedConv {
+    float* w = nullptr;
+    float* bias = nullptr;
+    int cout = 0, cin = 0, cin_pad = 0, KH = 0, KW = 0, Ktot = 0, rows = 0;
+    bool gather = false;
+};
+
+struct Arena {
+    char* base = nullptr;
+    size_t off = 0, cap = 0;
+    bool measure = true;
+    float* f(size_t nfloats) { return reinterpret_cast<float*>(raw(nfloats * sizeof(float))); }
+    void* raw(size_t bytes) {
+        const size_t a = (off + 255) & ~size_t(255);
+        off = a + bytes;
+        if (measure) return reinterpret_cast<void*>(size_t(256));   // non-null placeholder
+        return base + a;
+    }
+};
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+struct cf_handle {
+    cf_config cfg{};
+    std::string err;
+    std::map<std::string, RawWeight> raw;
+    std::map<std::string, PackedConv> conv;
+    float* lambda = nullptr;   // [2*base]
+    std::vector<void*> owned;  // hipMalloc'ed weight buffers
+    bool finalized = false;
+
+    // geometry
+    int B = 0, H = 0, W = 0, h = 0, w = 0;       // full / half resolution
+    int padH = 0, padW = 0, Hp = 0, Wp = 0;      // ImagePadder(min_size=32): top/left zero pad
+    int H1 = 0, W1 = 0, H2 = 0, W2 = 0, h8 = 0, w8 = 0, N = 0;
+    int bc = 0;                                  // base channels
+
+    // workspace
+    Arena arena;
+    void* arena_mem = nullptr;
+    // CISTA
+    float *xcat = nullptr, *x1 = nullptr, *ifbuf = nullptr, *z0 = nullptr, *xt = nullptr, *recx = nullptr, *gbuf = nullptr,
+          *up = nullptr, *zeros = nullptr;
+    // wrapper
+    float *warpedI = nullptr, *zwarp = nullptr;
+    int* flag = nullptr;
+    // flow net
+    float *encA = nullptr, *encB = nullptr, *encC = nullptr, *encD = nullptr, *encStats = nullptr, *encStats2 = nullptr;
+    double* encPartial = nullptr;
+    float *fmap1 = nullptr, *emap = nullptr, *fcat = nullptr, *pfmap2 = nullptr, *net = nullptr, *inp = nullptr;
+    float* corr[4] = {nullptr, nullptr, nullptr, nullptr};
+    int clh[4] = {0, 0, 0, 0}, clw[4] = {0, 0, 0, 0};
+    float *coords1 = nullptr, *corrfeat = nullptr, *c1buf = nullptr, *mcat = nullptr, *e1buf = nullptr, *f1buf = nullptr,
+          *motion = nullptr, *zbuf = nullptr, *rh = nullptr, *fh = nullptr;
+    static constexpr int CORR_LD = 336;   // 4*81 = 324 correlation channels padded to a multiple of 16
+
+    int fail(int code, const std::string& msg) {
+        err = msg;
+        return code;
+    }
+};
+
+#define CF_HIP(h, expr)                                                                              \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess)                                                                        \
+            return (h)->fail(CF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e) + " @" + \
+                                             std::to_string(__LINE__));                              \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// workspace layout
+// ---------------------------------------------------------------------------------------------
+static void setup_buffers(cf_handle* H_) {
+    cf_handle& s = *H_;
+    Arena& a = s.arena;
+    a.off = 0;
+    const size_t B = s.B, HW = (size_t)s.H * s.W, hw = (size_t)s.h * s.w, bc = s.bc;
+    s.flag = reinterpret_cast<int*>(a.raw(256));
+    s.zeros = a.f(B * hw * 2 * bc);
+    s.xcat = a.f(B * HW * bc);
+    s.x1 = a.f(B * hw * bc);
+    s.ifbuf = a.f(B * hw * 4 * bc);
+    s.z0 = a.f(B * hw * 2 * bc);
+    s.xt = a.f(B * hw * bc);
+    s.recx = a.f(B * hw * bc);
+    s.gbuf = a.f(B * hw * 4 * bc);
+    s.up = a.f(B * HW * bc);
+    s.warpedI = a.f(B * HW);
+    s.zwarp = a.f(B * hw * 2 * bc);
+    if (s.cfg.mode == CF_MODE_EIFLOW) {
+        const size_t P1 = (size_t)s.H1 * s.W1, N = s.N;
+        s.encA = a.f(B * P1 * 64);
+        s.encB = a.f(B * P1 * 64);
+        s.encC = a.f(B * P1 * 64);
+        s.encD = a.f(B * P1 * 64);
+        s.encStats = a.f(B * 256 * 2);
+        s.encStats2 = a.f(B * 256 * 2);
+        s.encPartial = reinterpret_cast<double*>(a.raw(sizeof(double) * (size_t)inorm_partial_doubles(s.B, (int)P1, 128)));
+        s.fmap1 = a.f(B * N * 256);
+        s.emap = a.f(B * N * 256);
+        s.fcat = a.f(B * N * 384);
+        s.pfmap2 = a.f(B * N * 256);
+        s.net = a.f(B * N * 128);
+        s.inp = a.f(B * N * 128);
+        int lh = s.h8, lw = s.w8;
+        for (int l = 0; l < 4; ++l) {
+            s.clh[l] = lh;
+            s.clw[l] = lw;
+            s.corr[l] = a.f(B * N * (size_t)lh * lw);
+            lh /= 2;
+            lw /= 2;
+        }
+        s.coords1 = a.f(B * 2 * N);
+        s.corrfeat = a.f(B * N * cf_handle::CORR_LD);
+        s.c1buf = a.f(B * N * 256);
+        s.mcat = a.f(B * N * 320);
+        s.e1buf = a.f(B * N * 128);
+        s.f1buf = a.f(B * N * 128);
+        s.motion = a.f(B * N * 128);
+        s.zbuf = a.f(B * N * 128);
+        s.rh = a.f(B * N * 128);
+        s.fh = a.f(B * N * 256);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv descriptor helpers
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct Seg {
+    const float* p;
+    int c, ld;
+    long bs;
+};
+
+ConvParams base_params() {
+    ConvParams p;
+    memset(&p, 0, sizeof(p));
+    p.out_cs = 1;
+    p.aux0_cs = 1;
+    p.g_scale = 1.f;
+    p.scale = 1.f;
+    return p;
+}
+
+// NHWC conv: input (Hin,Win) -> output (Ho,Wo)
+ConvParams nhwc_conv(const PackedConv& pc, std::initializer_list<Seg> segs, int Hin, int Win, int Ho, int Wo, int stride,
+                     int padT, int padL, int pad_mode, float* out, int out_ld, long out_bs, int epi) {
+    ConvParams p = base_params();
+    int i = 0;
+    for (const Seg& sg : segs) {
+        p.in[i] = sg.p;
+        p.seg_c[i] = sg.c;
+        p.seg_ld[i] = sg.ld;
+        p.seg_bs[i] = sg.bs;
+        ++i;
+    }
+    p.nseg = i;
+    p.Hin = Hin; p.Win = Win; p.Hsrc = Hin; p.Wsrc = Win; p.Ho = Ho; p.Wo = Wo;
+    p.KH = pc.KH; p.KW = pc.KW; p.stride = stride; p.padT = padT; p.padL = padL; p.pad_mode = pad_mode;
+    p.a_mode = A_NHWC;
+    p.w = pc.w; p.w_bs = 0; p.w_rows = pc.rows; p.Ktot = pc.Ktot; p.cin_pad = pc.cin_pad; p.bias = pc.bias;
+    p.out = out; p.out_ld = out_ld; p.out_bs = out_bs; p.cout = pc.cout; p.epi = epi;
+    return p;
+}
+
+// planar small-Cin conv (ImagePadder offsets folded in)
+ConvParams gather_conv(const PackedConv& pc, const float* in, int Cin, int Hsrc, int Wsrc, int offy, int offx,
+                       float scale, float shift, int subgrid, int Ho, int Wo, int stride, int padT, int padL,
+                       int pad_mode, float* out, int out_ld, long out_bs, int epi) {
+    ConvParams p = base_params();
+    p.in[0] = in; p.nseg = 1; p.seg_bs[0] = (long)Cin * Hsrc * Wsrc;
+    p.Hsrc = Hsrc; p.Wsrc = Wsrc; p.Hin = Hsrc + offy; p.Win = Wsrc + offx; p.Ho = Ho; p.Wo = Wo;
+    p.KH = pc.KH; p.KW = pc.KW; p.stride = stride; p.padT = padT; p.padL = padL; p.pad_mode = pad_mode;
+    p.a_mode = A_GATHER;
+    p.g_cin = Cin; p.g_offy = offy; p.g_offx = offx; p.g_scale = scale; p.g_shift = shift; p.g_subgrid = subgrid;
+    p.w = pc.w; p.w_rows = pc.rows; p.Ktot = pc.Ktot; p.cin_pad = 0; p.bias = pc.bias;
+    p.out = out; p.out_ld = out_ld; p.out_bs = out_bs; p.cout = pc.cout; p.epi = epi;
+    return p;
+}
+
+void set_aux0(ConvParams& p, const float* a, int ld, long bs, int cs = 1) { p.aux0 = a; p.aux0_ld = ld; p.aux0_bs = bs; p.aux0_cs = cs; }
+void set_aux1(ConvParams& p, const float* a, int ld, long bs) { p.aux1 = a; p.aux1_ld = ld; p.aux1_bs = bs; }
+void set_aux2(ConvParams& p, const float* a, int ld, long bs) { p.aux2 = a; p.aux2_ld = ld; p.aux2_bs = bs; }
+void set_out2(ConvParams& p, float* a, int ld, long bs) { p.out2 = a; p.out2_ld = ld; p.out2_bs = bs; }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// weight packing
+// ---------------------------------------------------------------------------------------------
+static const RawWeight* find_raw(cf_handle* h, const std::string& name) {
+    auto it = h->raw.find(name);
+    return it == h->raw.end() ? nullptr : &it->second;
+}
+
+// Packs `prefix`.weight/.bias (OIHW) as rows [row0, row0+Cout) of the conv registered under `key`.
+// total_rows > 0 on the first call allocates the packed matrix; bn_prefix folds an eval BatchNorm.
+static int pack_conv(cf_handle* h, const std::string& key, const std::string& prefix, bool gather, int row0,
+                     int total_rows, const std::string& bn_prefix, hipStream_t st) {
+    const RawWeight* wt = find_raw(h, prefix + ".weight");
+    const RawWeight* bs = find_raw(h, prefix + ".bias");
+    if (!wt || wt->shape.size() != 4) return h->fail(CF_ERR_WEIGHT, "missing or non-4D weight: " + prefix + ".weight");
+    const int Cout = (int)wt->shape[0], Cin = (int)wt->shape[1], KH = (int)wt->shape[2], KW = (int)wt->shape[3];
+    if (bs && (bs->shape.size() != 1 || bs->shape[0] != Cout)) return h->fail(CF_ERR_WEIGHT, "bad bias shape: " + prefix);
+    PackedConv& pc = h->conv[key];
+    if (!pc.w) {
+        pc.cin = Cin; pc.KH = KH; pc.KW = KW; pc.gather = gather;
+        pc.cin_pad = gather ? 0 : round_up(Cin, 16);
+        pc.Ktot = gather ? round_up(KH * KW * Cin, 16) : KH * KW * pc.cin_pad;
+        pc.cout = total_rows > 0 ? total_rows : Cout;
+        pc.rows = round_up(pc.cout, 128);
+        const size_t wbytes = (size_t)pc.rows * pc.Ktot * sizeof(float);
+        CF_HIP(h, hipMalloc(reinterpret_cast<void**>(&pc.w), wbytes));
+        h->owned.push_back(pc.w);
+        CF_HIP(h, hipMalloc(reinterpret_cast<void**>(&pc.bias), pc.rows * sizeof(float)));
+        h->owned.push_back(pc.bias);
+        CF_HIP(h, hipMemsetAsync(pc.w, 0, wbytes, st));
+        CF_HIP(h, hipMemsetAsync(pc.bias, 0, pc.rows * sizeof(float), st));
+    } else {
+        if (pc.cin != Cin || pc.KH != KH || pc.KW != KW) return h->fail(CF_ERR_WEIGHT, "stacked conv shape mismatch: " + prefix);
+    }
+    if (row0 + Cout > pc.rows) return h->fail(CF_ERR_WEIGHT, "stacked conv overflows: " + prefix);
+    const float *bw = nullptr, *bb = nullptr, *bm = nullptr, *bv = nullptr;
+    if (!bn_prefix.empty()) {
+        const RawWeight* r0 = find_raw(h, bn_prefix + ".weight");
+        const RawWeight* r1 = find_raw(h, bn_prefix + ".bias");
+        const RawWeight* r2 = find_raw(h, bn_prefix + ".running_mean");
+        const RawWeight* r3 = find_raw(h, bn_prefix + ".running_var");
+        if (!r0 || !r1 || !r2 || !r3) return h->fail(CF_ERR_WEIGHT, "missing BatchNorm tensors: " + bn_prefix);
+        if (r0->numel() != Cout || r1->numel() != Cout || r2->numel() != Cout || r3->numel() != Cout)
+            return h->fail(CF_ERR_WEIGHT, "bad BatchNorm shape: " + bn_prefix);
+        bw = r0->ptr; bb = r1->ptr; bm = r2->ptr; bv = r3->ptr;
+    }
+    CF_HIP(h, launch_pack_weight(wt->ptr, pc.w, Cout, Cin, KH, KW, pc.cin_pad, pc.Ktot, row0, gather ? 1 : 0, bw, bb, bm,
+                                 bv, 1e-5f, bs ? bs->ptr : nullptr, pc.bias, st));
+    return CF_OK;
+}
+
+static int pack_encoder(cf_handle* h, const std::string& pre, bool bn, hipStream_t st) {
+    int rc;
+    auto P = [&](const std::string& key, const std::string& name, bool gather, const std::string& bnname) -> int {
+        return pack_conv(h, pre + "." + key, pre + "." + name, gather, 0, 0, bn ? pre + "." + bnname : std::string(), st);
+    };
+    if ((rc = P("conv1", "conv1", true, "norm1"))) return rc;
+    for (int L = 1; L <= 3; ++L) {
+        for (int blk = 0; blk < 2; ++blk) {
+            const std::string b = "layer" + std::to_string(L) + "." + std::to_string(blk);
+            if ((rc = P(b + ".conv1", b + ".conv1", false, b + ".norm1"))) return rc;
+            if ((rc = P(b + ".conv2", b + ".conv2", false, b + ".norm2"))) return rc;
+            if (L > 1 && blk == 0)
+                if ((rc = P(b + ".downsample.0", b + ".downsample.0", false, b + ".downsample.1"))) return rc;
+        }
+    }
+    return pack_conv(h, pre + ".conv2", pre + ".conv2", false, 0, 0, "", st);
+}
+
+extern "C" int cf_load_weights(cf_handle* h, const char* name, const void* dev_ptr, const int64_t* shape, int ndim) {
+    if (!h) return CF_ERR_ARG;
+    if (!name || !dev_ptr || ndim < 0 || ndim > 8 || (ndim > 0 && !shape)) return h->fail(CF_ERR_ARG, "cf_load_weights: bad argument");
+    RawWeight r;
+    r.ptr = static_cast<const float*>(dev_ptr);
+    r.shape.assign(shape, shape + ndim);
+    h->raw[name] = r;
+    h->finalized = false;
+    return CF_OK;
+}
+
+extern "C" int cf_finalize_weights(cf_handle* h, void* stream) {
+    if (!h) return CF_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    CF_HIP(h, hipSetDevice(h->cfg.device));
+    for (void* p : h->owned) (void)hipFree(p);
+    h->owned.clear();
+    h->conv.clear();
+    h->lambda = nullptr;
+    int rc;
+    const std::string cn = (h->cfg.mode == CF_MODE_CISTA && !find_raw(h, "cista_net.We.conv2d.weight")) ? "" : "cista_net.";
+    auto C = [&](const std::string& key, const std::string& name, bool gather) -> int {
+        return pack_conv(h, "cista." + key, cn + name, gather, 0, 0, "", st);
+    };
+    // CistaLSTCNet (e2v_model.py:21-44); lista_blocks.0..4 alias one IstaBlock (:34-35)
+    if ((rc = C("We", "We.conv2d", true))) return rc;
+    if ((rc = C("Wi", "Wi.conv2d", true))) return rc;
+    if ((rc = C("W0", "W0.conv2d", false))) return rc;
+    if ((rc = C("gates", "P0.gates", false))) return rc;
+    if ((rc = C("out_gates", "P0.out_gates", false))) return rc;
+    if ((rc = C("P0", "P0.P0", false))) return rc;
+    if ((rc = C("D", "lista_blocks.0.D.conv2d", false))) return rc;
+    if ((rc = C("P", "lista_blocks.0.P.conv2d", false))) return rc;
+    if ((rc = C("Dg", "Dg.conv.conv2d", false))) return rc;
+    if ((rc = C("Gates", "Dg.recurrent_block.Gates", false))) return rc;
+    if ((rc = C("upsamp", "upsamp_conv.conv2d", false))) return rc;
+    if ((rc = C("final", "final_conv.conv2d", false))) return rc;
+    {
+        const RawWeight* lam = find_raw(h, cn + "lista_blocks.0.Lambda");
+        if (!lam || lam->numel() != 2 * h->bc) return h->fail(CF_ERR_WEIGHT, "missing/bad Lambda");
+        CF_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->lambda), lam->numel() * sizeof(float)));
+        h->owned.push_back(h->lambda);
+        CF_HIP(h, hipMemcpyAsync(h->lambda, lam->ptr, lam->numel() * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    if (h->cfg.mode == CF_MODE_EIFLOW) {
+        const std::string f = "event_flownet.";
+        if ((rc = pack_encoder(h, f + "fnet", false, st))) return rc;
+        if ((rc = pack_encoder(h, f + "enet", false, st))) return rc;
+        if ((rc = pack_encoder(h, f + "cnet", true, st))) return rc;
+        auto F = [&](const std::string& key, const std::string& name, bool gather) -> int {
+            return pack_conv(h, key, f + name, gather, 0, 0, "", st);
+        };
+        if ((rc = F("fusion.conv1", "fusion.conv1", false))) return rc;
+        if ((rc = F("fusion.conv2", "fusion.conv2", false))) return rc;
+        if ((rc = F("fusion.convo", "fusion.convo", false))) return rc;
+        const std::string e = "update_block.encoder.";
+        if ((rc = F("convc1", e + "convc1", false))) return rc;
+        if ((rc = F("convc2", e + "convc2", false))) return rc;
+        if ((rc = F("conve1", e + "conve1", false))) return rc;
+        if ((rc = F("conve2", e + "conve2", false))) return rc;
+        if ((rc = F("convf1", e + "convf1", true))) return rc;
+        if ((rc = F("convf2", e + "convf2", false))) return rc;
+        if ((rc = F("menc.conv", e + "conv", false))) return rc;
+        const std::string g = f + "update_block.gru.";
+        // z | r stacked into one 256-row matrix per pass (with_event_updater.py:54-65)
+        if ((rc = pack_conv(h, "gru.zr1", g + "convz1", false, 0, 256, "", st))) return rc;
+        if ((rc = pack_conv(h, "gru.zr1", g + "convr1", false, 128, 256, "", st))) return rc;
+        if ((rc = pack_conv(h, "gru.q1", g + "convq1", false, 0, 0, "", st))) return rc;
+        if ((rc = pack_conv(h, "gru.zr2", g + "convz2", false, 0, 256, "", st))) return rc;
+        if ((rc = pack_conv(h, "gru.zr2", g + "convr2", false, 128, 256, "", st))) return rc;
+        if ((rc = pack_conv(h, "gru.q2", g + "convq2", false, 0, 0, "", st))) return rc;
+        if ((rc = F("fh.conv1", "update_block.flow_head.conv1", false))) return rc;
+        if ((rc = F("fh.conv2", "update_block.flow_head.conv2", false))) return rc;
+        if (h->conv["convc1"].cin_pad != cf_handle::CORR_LD) return h->fail(CF_ERR_WEIGHT, "convc1 expects 324 input channels");
+    }
+    // the announced pointers may die after this call: drain the packing kernels
+    CF_HIP(h, hipStreamSynchronize(st));
+    h->raw.clear();
+    h->finalized = true;
+    return CF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// lifetime
+// ---------------------------------------------------------------------------------------------
+extern "C" int cf_create(cf_handle** out, const cf_config* cfg) {
+    if (!out || !cfg) {
+        g_create_error = "cf_create: null argument";
+        return CF_ERR_ARG;
+    }
+    *out = nullptr;
+    auto bad = [&](const char* m) {
+        g_create_error = m;
+        return CF_ERR_ARG;
+    };
+    if (cfg->batch < 1 || cfg->height < 8 || cfg->width < 8) return bad("cf_create: bad batch/height/width");
+    if ((cfg->height & 1) || (cfg->width & 1)) return bad("cf_create: height and width must be even (W0 stride 2 vs x2 upsample)");
+    if (cfg->num_bins != 5 && cfg->num_bins < 1) return bad("cf_create: bad num_bins");
+    if (cfg->base_channels < 32 || (cfg->base_channels % 32) != 0) return bad("cf_create: base_channels must be a multiple of 32");
+    if (cfg->depth < 1) return bad("cf_create: bad depth");
+    if (cfg->mode != CF_MODE_CISTA && cfg->mode != CF_MODE_EIFLOW) {
+        g_create_error = "cf_create: mode not built yet (eraft / idnet)";
+        return CF_ERR_UNSUPPORTED;
+    }
+    if (cfg->mode == CF_MODE_EIFLOW && cfg->iters < 1) return bad("cf_create: bad iters");
+    cf_handle* h = new cf_handle();
+    h->cfg = *cfg;
+    h->B = cfg->batch; h->H = cfg->height; h->W = cfg->width; h->h = cfg->height / 2; h->w = cfg->width / 2;
+    h->bc = cfg->base_channels;
+    // ImagePadder(min_size=32), DCEIFlow.py:52 / image_process.py:78-79
+    h->padH = (32 - h->H % 32) % 32;
+    h->padW = (32 - h->W % 32) % 32;
+    h->Hp = h->H + h->padH; h->Wp = h->W + h->padW;
+    h->H1 = h->Hp / 2; h->W1 = h->Wp / 2; h->H2 = h->Hp / 4; h->W2 = h->Wp / 4; h->h8 = h->Hp / 8; h->w8 = h->Wp / 8;
+    h->N = h->h8 * h->w8;
+    if (cfg->mode == CF_MODE_EIFLOW && (h->h8 < 8 || h->w8 < 8)) {
+        delete h;
+        return bad("cf_create: padded image must be >= 64x64 for the 4-level correlation pyramid");
+    }
+    if (hipSetDevice(cfg->device) != hipSuccess) {
+        delete h;
+        g_create_error = "cf_create: hipSetDevice failed (no GPU?)";
+        return CF_ERR_HIP;
+    }
+    h->arena.measure = true;
+    setup_buffers(h);
+    const size_t bytes = h->arena.off + 256;
+    if (hipMalloc(&h->arena_mem, bytes) != hipSuccess) {
+        delete h;
+        g_create_error = "cf_create: workspace hipMalloc failed";
+        return CF_ERR_HIP;
+    }
+    // zero the arena once: `zeros`, and the pad channels of concat buffers, must be 0 (not NaN)
+    if (hipMemset(h->arena_mem, 0, bytes) != hipSuccess) {
+        (void)hipFree(h->arena_mem);
+        delete h;
+        g_create_error = "cf_create: workspace hipMemset failed";
+        return CF_ERR_HIP;
+    }
+    h->arena.base = static_cast<char*>(h->arena_mem);
+    h->arena.cap = bytes;
+    h->arena.measure = false;
+    setup_buffers(h);
+    *out = h;
+    return CF_OK;
+}
+
+extern "C" void cf_destroy(cf_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    for (void* p : h->owned) (void)hipFree(p);
+    if (h->arena_mem) (void)hipFree(h->arena_mem);
+    delete h;
+}
+
+extern "C" const char* cf_last_error(const cf_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+extern "C" size_t cf_workspace_bytes(const cf_handle* h) { return h ? h->arena.cap : 0; }
+
+// ---------------------------------------------------------------------------------------------
+// a4 warp
+// ---------------------------------------------------------------------------------------------
+extern "C" int cf_warp(cf_handle* h, const float* img, const float* flow, float* out, int B, int C, int H, int W, int Hf,
+                       int Wf, int mode, void* stream) {
+    if (!h) return CF_ERR_ARG;
+    if (!img || !flow || !out || B < 1 || C < 1 || H < 2 || W < 2) return h->fail(CF_ERR_ARG, "cf_warp: bad argument");
+    CF_HIP(h, launch_warp(img, C, (long)H * W * C, flow, Hf, Wf, out, C, (long)H * W * C, B, C, H, W,
+                          mode == CF_WARP_BACKWARD ? 1 : 0, nullptr, static_cast<hipStream_t>(stream)));
+    return CF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a3 CISTA-LSTC
+// ---------------------------------------------------------------------------------------------
+static int cista_forward(cf_handle* h, const float* ev, const float* img, const float* c_prev, const float* z_prev,
+                         const float* h_prev, const float* cc_prev, float* I_out, float* c_out, float* z_out,
+                         float* h_out, float* cc_out, hipStream_t st) {
+    const int B = h->B, H = h->H, W = h->W, hh = h->h, ww = h->w, bc = h->bc, bins = h->cfg.num_bins;
+    const long HW = (long)H * W, hw = (long)hh * ww;
+    const int c2 = 2 * bc;
+    if (!z_prev) z_prev = h->zeros;
+    if (!c_prev) c_prev = h->zeros;
+    if (!h_prev) h_prev = h->zeros;
+    // x_E = We(events), x_I = Wi(prev_image), x1 = W0(cat)      e2v_model.py:69-73
+    {
+        ConvParams p = gather_conv(h->conv["cista.We"], ev, bins, H, W, 0, 0, 1.f, 0.f, 0, H, W, 1, 1, 1, 1, h->xcat, bc,
+                                   HW * bc, EPI_NONE);
+        CF_HIP(h, launch_conv(p, B, st));
+        ConvParams q = gather_conv(h->conv["cista.Wi"], img, 1, H, W, 0, 0, 1.f, 0.f, 0, H, W, 1, 1, 1, 1,
+                                   h->xcat + bc / 2, bc, HW * bc, EPI_NONE);
+        CF_HIP(h, launch_conv(q, B, st));
+        ConvParams r = nhwc_conv(h->conv["cista.W0"], {{h->xcat, bc, bc, HW * bc}}, H, W, hh, ww, 2, 1, 1, 1, h->x1, bc,
+                                 hw * bc, EPI_NONE);
+        CF_HIP(h, launch_conv(r, B, st));
+    }
+    // ConvLSTC  base_layers.py:52-71
+    {
+        ConvParams g = nhwc_conv(h->conv["cista.gates"], {{h->x1, bc, bc, hw * bc}, {z_prev, c2, c2, hw * c2}}, hh, ww, hh,
+                                 ww, 1, 1, 1, 1, h->ifbuf, 2 * c2, hw * 2 * c2, EPI_SIGMOID);
+        CF_HIP(h, launch_conv(g, B, st));
+        ConvParams p0 = nhwc_conv(h->conv["cista.P0"], {{h->x1, bc, bc, hw * bc}}, hh, ww, hh, ww, 1, 1, 1, 1, h->z0, c2,
+                                  hw * c2, EPI_NONE);
+        CF_HIP(h, launch_conv(p0, B, st));
+        ConvParams og = nhwc_conv(h->conv["cista.out_gates"], {{h->z0, c2, c2, hw * c2}, {z_prev, c2, c2, hw * c2}}, hh, ww,
+                                  hh, ww, 1, 1, 1, 1, z_out, c2, hw * c2, EPI_LSTC);
+        og.split = c2;
+        set_aux0(og, h->ifbuf, 2 * c2, hw * 2 * c2);
+        set_aux1(og, h->z0, c2, hw * c2);
+        set_aux2(og, c_prev, c2, hw * c2);
+        set_out2(og, c_out, c2, hw * c2);
+        CF_HIP(h, launch_conv(og, B, st));
+    }
+    // unrolled ISTA, shared D / P / Lambda   e2v_model.py:81-87
+    for (int i = 0; i < h->cfg.depth; ++i) {
+        ConvParams d = nhwc_conv(h->conv["cista.D"], {{z_out, c2, c2, hw * c2}}, hh, ww, hh, ww, 1, 1, 1, 1, h->xt, bc,
+                                 hw * bc, EPI_SUB_FROM_AUX);
+        set_aux0(d, h->x1, bc, hw * bc);
+        CF_HIP(h, launch_conv(d, B, st));
+        ConvParams p = nhwc_conv(h->conv["cista.P"], {{h->xt, bc, bc, hw * bc}}, hh, ww, hh, ww, 1, 1, 1, 1, z_out, c2,
+                                 hw * c2, EPI_ADD_AUX_SHRINK);
+        set_aux0(p, z_out, c2, hw * c2);
+        p.lam = h->lambda;
+        CF_HIP(h, launch_conv(p, B, st));
+    }
+    // Dg: conv+relu, ConvLSTM   base_layers.py:223-227, 90-132
+    {
+        ConvParams d = nhwc_conv(h->conv["cista.Dg"], {{z_out, c2, c2, hw * c2}}, hh, ww, hh, ww, 1, 1, 1, 1, h->recx, bc,
+                                 hw * bc, EPI_RELU);
+        CF_HIP(h, launch_conv(d, B, st));
+        ConvParams g = nhwc_conv(h->conv["cista.Gates"], {{h->recx, bc, bc, hw * bc}, {h_prev, bc, bc, hw * bc}}, hh, ww,
+                                 hh, ww, 1, 1, 1, 1, h->gbuf, 4 * bc, hw * 4 * bc, EPI_LSTM_ACT);
+        g.split = 3 * bc;
+        CF_HIP(h, launch_conv(g, B, st));
+        CF_HIP(h, launch_lstm_cell(h->gbuf, 4 * bc, hw * 4 * bc, cc_prev, bc, hw * bc, h_out, bc, hw * bc, cc_out, bc,
+                                   hw * bc, B, (int)hw, bc, st));
+    }
+    // upsample x2 + reflect pad + conv + relu ; final conv + sigmoid   e2v_model.py:94-96
+    {
+        ConvParams u = nhwc_conv(h->conv["cista.upsamp"], {{h_out, bc, bc, hw * bc}}, 2 * hh, 2 * ww, H, W, 1, 1, 1, 1, h->up,
+                                 bc, HW * bc, EPI_RELU);
+        u.a_mode = A_UPS2X;
+        u.Hsrc = hh;
+        u.Wsrc = ww;
+        CF_HIP(h, launch_conv(u, B, st));
+        ConvParams f = nhwc_conv(h->conv["cista.final"], {{h->up, bc, bc, HW * bc}}, H, W, H, W, 1, 1, 1, 1, I_out, 1, HW,
+                                 EPI_SIGMOID);
+        CF_HIP(h, launch_conv(f, B, st));
+    }
+    return CF_OK;
+}
+
+extern "C" int cf_cista_forward(cf_handle* h, const float* ev, const float* img, const float* c_prev, const float* z_prev,
+                                const float* h_prev, const float* cc_prev, float* I_out, float* c_out, float* z_out,
+                                float* h_out, float* cc_out, void* stream) {
+    if (!h) return CF_ERR_ARG;
+    if (!h->finalized) return h->fail(CF_ERR_STATE, "cf_cista_forward: weights not finalised");
+    if (!ev || !img || !I_out || !c_out || !z_out || !h_out || !cc_out) return h->fail(CF_ERR_ARG, "cf_cista_forward: null pointer");
+    if ((h_prev == nullptr) != (cc_prev == nullptr)) return h->fail(CF_ERR_ARG, "cf_cista_forward: h_prev/cc_prev must come together");
+    CF_HIP(h, hipSetDevice(h->cfg.device));
+    return cista_forward(h, ev, img, c_prev, z_prev, h_prev, cc_prev, I_out, c_out, z_out, h_out, cc_out,
+                         static_cast<hipStream_t>(stream));
+}
+
+// ---------------------------------------------------------------------------------------------
+// BasicEncoder  raft_encoder.py:179-203
+// ---------------------------------------------------------------------------------------------
+// in: planar [B][Cin][H][W] (un-padded); out: NHWC [B][N][256] (or tanh|relu split when out2 != null)
+static int encoder_forward(cf_handle* h, const std::string& pre, bool bn, const float* in, int Cin, float scale,
+                           float shift, float* out, float* out2, hipStream_t st) {
+    const int B = h->B;
+    const float eps = 1e-5f;
+    int Hc = h->H1, Wc = h->W1;   // current resolution
+    float *A = h->encA, *Bf = h->encB, *Cf = h->encC, *Df = h->encD;
+    auto K = [&](const std::string& k) -> const PackedConv& { return h->conv[pre + "." + k]; };
+    // conv1 7x7 s2 (+norm1 + relu)
+    {
+        ConvParams p = gather_conv(K("conv1"), in, Cin, h->H, h->W, h->padH, h->padW, scale, shift, 0, Hc, Wc, 2, 3, 3, 0,
+                                   bn ? A : Bf, 64, (long)Hc * Wc * 64, bn ? EPI_RELU : EPI_NONE);
+        CF_HIP(h, launch_conv(p, B, st));
+        if (!bn) {
+            CF_HIP(h, launch_inorm_stats(Bf, 64, (long)Hc * Wc * 64, B, Hc * Wc, 64, eps, h->encPartial, h->encStats, st));
+            CF_HIP(h, launch_inorm_apply(Bf, 64, (long)Hc * Wc * 64, h->encStats, nullptr, 0, 0, nullptr, A, 64,
+                                         (long)Hc * Wc * 64, B, Hc * Wc, 64, st));
+        }
+    }
+    // x lives in A; scratch Bf, Cf, Df
+    int Cx = 64;
+    const int dims[3] = {64, 96, 128};
+    for (int L = 1; L <= 3; ++L) {
+        const int Cd = dims[L - 1];
+        for (int blk = 0; blk < 2; ++blk) {
+            const std::string b = "layer" + std::to_string(L) + "." + std::to_string(blk);
+            const int stride = (L > 1 && blk == 0) ? 2 : 1;
+            const int Ho = Hc / stride, Wo = Wc / stride;
+            const long ibs = (long)Hc * Wc * Cx, obs = (long)Ho * Wo * Cd;
+            if (bn) {
+                // y = relu(bn1(conv1(x))) ; y = relu(bn2(conv2(y))) ; out = relu(x' + y)
+                ConvParams c1 = nhwc_conv(K(b + ".conv1"), {{A, Cx, Cx, ibs}}, Hc, Wc, Ho, Wo, stride, 1, 1, 0, Bf, Cd, obs, EPI_RELU);
+                CF_HIP(h, launch_conv(c1, B, st));
+                const float* res = A;
+                int res_ld = Cx;
+                long res_bs = ibs;
+                if (stride != 1) {
+                    ConvParams ds = nhwc_conv(K(b + ".downsample.0"), {{A, Cx, Cx, ibs}}, Hc, Wc, Ho, Wo, stride, 0, 0, 0, Cf, Cd, obs, EPI_NONE);
+                    CF_HIP(h, launch_conv(ds, B, st));
+                    res = Cf; res_ld = Cd; res_bs = obs;
+                }
+                ConvParams c2 = nhwc_conv(K(b + ".conv2"), {{Bf, Cd, Cd, obs}}, Ho, Wo, Ho, Wo, 1, 1, 1, 0, Df, Cd, obs, EPI_RELU_ADD_AUX_RELU);
+                set_aux0(c2, res, res_ld, res_bs);
+                CF_HIP(h, launch_conv(c2, B, st));
+                std::swap(A, Df);
+            } else {
+                ConvParams c1 = nhwc_conv(K(b + ".conv1"), {{A, Cx, Cx, ibs}}, Hc, Wc, Ho, Wo, stride, 1, 1, 0, Bf, Cd, obs, EPI_NONE);
+                CF_HIP(h, launch_conv(c1, B, st));
+                CF_HIP(h, launch_inorm_stats(Bf, Cd, obs, B, Ho * Wo, Cd, eps, h->encPartial, h->encStats, st));
+                CF_HIP(h, launch_inorm_apply(Bf, Cd, obs, h->encStats, nullptr, 0, 0, nullptr, Cf, Cd, obs, B, Ho * Wo, Cd, st));
+                ConvParams c2 = nhwc_conv(K(b + ".conv2"), {{Cf, Cd, Cd, obs}}, Ho, Wo, Ho, Wo, 1, 1, 1, 0, Bf, Cd, obs, EPI_NONE);
+                CF_HIP(h, launch_conv(c2, B, st));
+                CF_HIP(h, launch_inorm_stats(Bf, Cd, obs, B, Ho * Wo, Cd, eps, h->encPartial, h->encStats, st));
+                const float* res = A;
+                int res_ld = Cx;
+                long res_bs = ibs;
+                const float* res_stats = nullptr;
+                if (stride != 1) {
+                    ConvParams ds = nhwc_conv(K(b + ".downsample.0"), {{A, Cx, Cx, ibs}}, Hc, Wc, Ho, Wo, stride, 0, 0, 0, Cf, Cd, obs, EPI_NONE);
+                    CF_HIP(h, launch_conv(ds, B, st));
+                    CF_HIP(h, launch_inorm_stats(Cf, Cd, obs, B, Ho * Wo, Cd, eps, h->encPartial, h->encStats2, st));
+                    res = Cf; res_ld = Cd; res_bs = obs; res_stats = h->encStats2;
+                }
+                CF_HIP(h, launch_inorm_apply(Bf, Cd, obs, h->encStats, res, res_ld, res_bs, res_stats, Df, Cd, obs, B, Ho * Wo, Cd, st));
+                std::swap(A, Df);
+            }
+            Hc = Ho; Wc = Wo; Cx = Cd;
+        }
+    }
+    // conv2 1x1 128 -> 256
+    const long N = (long)Hc * Wc;
+    if (!out2) {
+        ConvParams c = nhwc_conv(K("conv2"), {{A, Cx, Cx, N * Cx}}, Hc, Wc, Hc, Wc, 1, 0, 0, 0, out, 256, N * 256, EPI_NONE);
+        CF_HIP(h, launch_conv(c, B, st));
+    } else {
+        // net, inp = split(cnet, [128,128]); tanh / relu   DCEIFlow.py:193-196
+        ConvParams c = nhwc_conv(K("conv2"), {{A, Cx, Cx, N * Cx}}, Hc, Wc, Hc, Wc, 1, 0, 0, 0, out, 128, N * 128, EPI_TANH_RELU_SPLIT);
+        c.split = 128;
+        set_out2(c, out2, 128, N * 128);
+        CF_HIP(h, launch_conv(c, B, st));
+    }
+    return CF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// DCEIFlow.forward  DCEIFlow.py:143-227 (image2 / reversed voxel branches are training-only)
+// ---------------------------------------------------------------------------------------------
+static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const float* flow_init, float* flow_final,
+                          float* flow_low, float* flow_preds, int* flag, hipStream_t st) {
+    const int B = h->B, h8 = h->h8, w8 = h->w8;
+    const long N = h->N;
+    int rc;
+    // encoders: emap = enet(pad(ev)); fmap1 = fnet(pad(2*I-1)); cnet(pad(2*I-1)) -> net, inp
+    if ((rc = encoder_forward(h, "event_flownet.enet", false, ev, h->cfg.num_bins, 1.f, 0.f, h->emap, nullptr, st))) return rc;
+    if ((rc = encoder_forward(h, "event_flownet.fnet", false, img, 1, 2.f, -1.f, h->fmap1, nullptr, st))) return rc;
+    if ((rc = encoder_forward(h, "event_flownet.cnet", true, img, 1, 2.f, -1.f, h->net, h->inp, st))) return rc;
+    // EIFusion  DCEIFlow.py:39-44
+    {
+        ConvParams a = nhwc_conv(h->conv["fusion.conv1"], {{h->fmap1, 256, 256, N * 256}}, h8, w8, h8, w8, 1, 0, 0, 0, h->fcat, 384, N * 384, EPI_RELU);
+        CF_HIP(h, launch_conv(a, B, st));
+        ConvParams b = nhwc_conv(h->conv["fusion.conv2"], {{h->emap, 256, 256, N * 256}}, h8, w8, h8, w8, 1, 0, 0, 0, h->fcat + 192, 384, N * 384, EPI_RELU);
+        CF_HIP(h, launch_conv(b, B, st));
+        ConvParams o = nhwc_conv(h->conv["fusion.convo"], {{h->fcat, 384, 384, N * 384}}, h8, w8, h8, w8, 1, 1, 1, 0, h->pfmap2, 256, N * 256, EPI_RELU_ADD_AUX);
+        set_aux0(o, h->fmap1, 256, N * 256);
+        CF_HIP(h, launch_conv(o, B, st));
+    }
+    // all-pairs correlation + pyramid   raft_corr.py:22-30,56-65
+    {
+        ConvParams p = base_params();
+        p.in[0] = h->fmap1; p.seg_c[0] = 256; p.seg_ld[0] = 256; p.seg_bs[0] = N * 256; p.nseg = 1;
+        p.Hin = h8; p.Win = w8; p.Hsrc = h8; p.Wsrc = w8; p.Ho = h8; p.Wo = w8;
+        p.KH = 1; p.KW = 1; p.stride = 1; p.a_mode = A_NHWC;
+        p.w = h->pfmap2; p.w_bs = N * 256; p.w_rows = (int)N; p.Ktot = 256; p.cin_pad = 256;
+        p.out = h->corr[0]; p.out_ld = (int)N; p.out_bs = N * N; p.cout = (int)N; p.epi = EPI_SCALE;
+        p.scale = 1.0f / sqrtf(256.f);
+        CF_HIP(h, launch_conv(p, B, st));
+        for (int l = 1; l < 4; ++l)
+            CF_HIP(h, launch_corr_pool(h->corr[l - 1], h->corr[l], (long)B * N, h->clh[l - 1], h->clw[l - 1], st));
+    }
+    // emap branch of the motion encoder is iteration-invariant (with_event_updater.py:105-106)
+    {
+        ConvParams a = nhwc_conv(h->conv["conve1"], {{h->emap, 256, 256, N * 256}}, h8, w8, h8, w8, 1, 0, 0, 0, h->e1buf, 128, N * 128, EPI_RELU);
+        CF_HIP(h, launch_conv(a, B, st));
+        ConvParams b = nhwc_conv(h->conv["conve2"], {{h->e1buf, 128, 128, N * 128}}, h8, w8, h8, w8, 1, 1, 1, 0, h->mcat + 192, 320, N * 320, EPI_RELU);
+        CF_HIP(h, launch_conv(b, B, st));
+    }
+    CF_HIP(h, launch_coords_init(h->coords1, flow_init, B, h8, w8, st));
+    if (flag) CF_HIP(h, hipMemsetAsync(flag, 0, sizeof(int), st));
+    const int iters = h->cfg.iters;
+    for (int it = 0; it < iters; ++it) {
+        // corr = corr_fn(coords1); flow = coords1 - coords0
+        LookupParams lp;
+        for (int l = 0; l < 4; ++l) { lp.lvl[l] = h->corr[l]; lp.lh[l] = h->clh[l]; lp.lw[l] = h->clw[l]; }
+        lp.coords1 = h->coords1; lp.out = h->corrfeat; lp.out_ld = cf_handle::CORR_LD;
+        lp.motion = h->motion; lp.mo_ld = 128; lp.mo_off = 126;
+        lp.B = B; lp.h8 = h8; lp.w8 = w8; lp.radius = 4; lp.nlevels = 4;
+        CF_HIP(h, launch_corr_lookup(lp, st));
+        // BasicMotionEncoder  with_event_updater.py:102-112
+        ConvParams c1 = nhwc_conv(h->conv["convc1"], {{h->corrfeat, cf_handle::CORR_LD, cf_handle::CORR_LD, N * cf_handle::CORR_LD}}, h8, w8, h8, w8, 1, 0, 0, 0, h->c1buf, 256, N * 256, EPI_RELU);
+        CF_HIP(h, launch_conv(c1, B, st));
+        ConvParams c2 = nhwc_conv(h->conv["convc2"], {{h->c1buf, 256, 256, N * 256}}, h8, w8, h8, w8, 1, 1, 1, 0, h->mcat, 320, N * 320, EPI_RELU);
+        CF_HIP(h, launch_conv(c2, B, st));
+        ConvParams f1 = gather_conv(h->conv["convf1"], h->coords1, 2, h8, w8, 0, 0, 1.f, 0.f, 1, h8, w8, 1, 3, 3, 0, h->f1buf, 128, N * 128, EPI_RELU);
+        CF_HIP(h, launch_conv(f1, B, st));
+        ConvParams f2 = nhwc_conv(h->conv["convf2"], {{h->f1buf, 128, 128, N * 128}}, h8, w8, h8, w8, 1, 1, 1, 0, h->mcat + 256, 320, N * 320, EPI_RELU);
+        CF_HIP(h, launch_conv(f2, B, st));
+        ConvParams mc = nhwc_conv(h->conv["menc.conv"], {{h->mcat, 320, 320, N * 320}}, h8, w8, h8, w8, 1, 1, 1, 0, h->motion, 128, N * 128, EPI_RELU);
+        CF_HIP(h, launch_conv(mc, B, st));
+        // SepConvGRU  with_event_updater.py:52-67 ; hx = cat(h, inp, motion)
+        for (int pass = 0; pass < 2; ++pass) {
+            const PackedConv& zr = h->conv[pass == 0 ? "gru.zr1" : "gru.zr2"];
+            const PackedConv& qq = h->conv[pass == 0 ? "gru.q1" : "gru.q2"];
+            const int pT = pass == 0 ? 0 : 2, pL = pass == 0 ? 2 : 0;
+            ConvParams a = nhwc_conv(zr, {{h->net, 128, 128, N * 128}, {h->inp, 128, 128, N * 128}, {h->motion, 128, 128, N * 128}}, h8, w8, h8, w8, 1, pT, pL, 0, h->zbuf, 128, N * 128, EPI_GRU_ZR);
+            a.split = 128;
+            set_aux0(a, h->net, 128, N * 128);
+            set_out2(a, h->rh, 128, N * 128);
+            CF_HIP(h, launch_conv(a, B, st));
+            ConvParams q = nhwc_conv(qq, {{h->rh, 128, 128, N * 128}, {h->inp, 128, 128, N * 128}, {h->motion, 128, 128, N * 128}}, h8, w8, h8, w8, 1, pT, pL, 0, h->net, 128, N * 128, EPI_GRU_Q);
+            set_aux0(q, h->zbuf, 128, N * 128);
+            set_aux1(q, h->net, 128, N * 128);
+            CF_HIP(h, launch_conv(q, B, st));
+        }
+        // FlowHead + coords1 += delta_flow   with_event_updater.py:13-14, DCEIFlow.py:218
+        ConvParams h1 = nhwc_conv(h->conv["fh.conv1"], {{h->net, 128, 128, N * 128}}, h8, w8, h8, w8, 1, 1, 1, 0, h->fh, 256, N * 256, EPI_RELU);
+        CF_HIP(h, launch_conv(h1, B, st));
+        ConvParams h2 = nhwc_conv(h->conv["fh.conv2"], {{h->fh, 256, 256, N * 256}}, h8, w8, h8, w8, 1, 1, 1, 0, h->coords1, 1, 2 * N, EPI_ADD_AUX);
+        h2.out_cs = (int)N;
+        set_aux0(h2, h->coords1, 1, 2 * N, (int)N);
+        CF_HIP(h, launch_conv(h2, B, st));
+        // upflow8 + unpad   DCEIFlow.py:222-227
+        const bool last = it == iters - 1;
+        float* up = flow_preds ? flow_preds + (long)it * B * 2 * h->Hp * h->Wp : nullptr;
+        if (last || up)
+            CF_HIP(h, launch_upflow(h->coords1, B, h8, w8, 8, up, last ? flow_final : nullptr, h->H, h->W, h->padH, h->padW,
+                                    last ? flag : nullptr, st));
+    }
+    if (flow_low) {
+        // flow_init of the returned dict = coords1 - coords0 at 1/8 resolution (DCEIFlow.py:297)
+        CF_HIP(h, launch_upflow(h->coords1, B, h8, w8, 1, flow_low, nullptr, 0, 0, 0, 0, nullptr, st));
+    }
+    return CF_OK;
+}
+
+extern "C" int cf_flow_forward(cf_handle* h, const float* in0, const float* in1, const float* flow_init, float* flow_final,
+                               float* flow_low, float* flow_preds, void* stream) {
+    if (!h) return CF_ERR_ARG;
+    if (!h->finalized) return h->fail(CF_ERR_STATE, "cf_flow_forward: weights not finalised");
+    if (h->cfg.mode != CF_MODE_EIFLOW) return h->fail(CF_ERR_UNSUPPORTED, "cf_flow_forward: handle has no flow network");
+    if (!in0 || !in1 || !flow_final) return h->fail(CF_ERR_ARG, "cf_flow_forward: null pointer");
+    CF_HIP(h, hipSetDevice(h->cfg.device));
+    return eiflow_forward(h, in0, in1, flow_init, flow_final, flow_low, flow_preds, h->flag, static_cast<hipStream_t>(stream));
+}
+
+// ---------------------------------------------------------------------------------------------
+// a5 wrapper   e2v_model.py:144-196
+// ---------------------------------------------------------------------------------------------
+extern "C" int cf_step(cf_handle* h, const float* in0, const float* in1, const float* rec_img0, const float* flow_init,
+                       const float* gt_flow, const float* c_prev, const float* z_prev, const float* h_prev,
+                       const float* cc_prev, float* I_out, float* flow_final, float* flow_low, float* flow_preds,
+                       float* z_warped_out, float* c_out, float* z_out, float* h_out, float* cc_out, void* stream) {
+    if (!h) return CF_ERR_ARG;
+    if (!h->finalized) return h->fail(CF_ERR_STATE, "cf_step: weights not finalised");
+    if (h->cfg.mode != CF_MODE_EIFLOW) return h->fail(CF_ERR_UNSUPPORTED, "cf_step: mode not built yet");
+    if (!in0 || !in1 || !rec_img0 || !I_out || !flow_final || !c_out || !z_out || !h_out || !cc_out)
+        return h->fail(CF_ERR_ARG, "cf_step: null pointer");
+    if ((h_prev == nullptr) != (cc_prev == nullptr)) return h->fail(CF_ERR_ARG, "cf_step: h_prev/cc_prev must come together");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    CF_HIP(h, hipSetDevice(h->cfg.device));
+    int rc;
+    // flow estimation from E_0^1 and the previous reconstruction (e2v_model.py:170-174)
+    if ((rc = eiflow_forward(h, in0, in1, flow_init, flow_final, flow_low, flow_preds, h->flag, st))) return rc;
+    const float* flow = flow_final;
+    if (gt_flow) {   // e2v_model.py:181-182
+        flow = gt_flow;
+        CF_HIP(h, launch_any_nonzero(gt_flow, (long)h->B * 2 * h->H * h->W, h->flag, st));
+    }
+    const int bwd = h->cfg.warp_mode == CF_WARP_BACKWARD ? 1 : 0;
+    const long HW = (long)h->H * h->W, hw = (long)h->h * h->w;
+    const int c2 = 2 * h->bc;
+    // `if not flow_final.any()` -> device flag; flag == 0 makes the warps pass-through copies (:184-191)
+    CF_HIP(h, launch_warp(rec_img0, 1, HW, flow, h->H, h->W, h->warpedI, 1, HW, h->B, 1, h->H, h->W, bwd, h->flag, st));
+    const float* zin = nullptr;
+    if (z_prev) {
+        float* zw = z_warped_out ? z_warped_out : h->zwarp;
+        CF_HIP(h, launch_warp(z_prev, c2, hw * c2, flow, h->H, h->W, zw, c2, hw * c2, h->B, c2, h->h, h->w, bwd, h->flag, st));
+        zin = zw;
+    }
+    return cista_forward(h, in0, h->warpedI, c_prev, zin, h_prev, cc_prev, I_out, c_out, z_out, h_out, cc_out, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// single-operator entry points for the parity tests
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct TmpBuf {
+    void* p = nullptr;
+    ~TmpBuf() { if (p) (void)hipFree(p); }
+};
+}  // namespace
+
+extern "C" int cf_op_conv2d(const float* in, int B, int Cin, int H, int W, const float* weight, const float* bias, int Cout,
+                            int KH, int KW, int stride, int padT, int padL, int pad_mode, int a_mode, int epi, int tile,
+                            float* out, void* stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!in || !weight || !out || B < 1 || Cin < 1 || Cout < 1 || stride < 1) return CF_ERR_ARG;
+    const bool gather = a_mode == A_GATHER;
+    if (!gather && (Cin % 16) != 0) return CF_ERR_ARG;
+    const int Hin = a_mode == A_UPS2X ? 2 * H : H, Win = a_mode == A_UPS2X ? 2 * W : W;
+    const int Ho = (Hin + 2 * padT - KH) / stride + 1, Wo = (Win + 2 * padL - KW) / stride + 1;
+    PackedConv pc;
+    pc.cin = Cin; pc.KH = KH; pc.KW = KW; pc.gather = gather; pc.cout = Cout;
+    pc.cin_pad = gather ? 0 : round_up(Cin, 16);
+    pc.Ktot = gather ? round_up(KH * KW * Cin, 16) : KH * KW * pc.cin_pad;
+    pc.rows = round_up(Cout, 128);
+    TmpBuf wb, bb;
+    if (hipMalloc(&wb.p, (size_t)pc.rows * pc.Ktot * sizeof(float)) != hipSuccess) return CF_ERR_HIP;
+    if (hipMalloc(&bb.p, pc.rows * sizeof(float)) != hipSuccess) return CF_ERR_HIP;
+    pc.w = static_cast<float*>(wb.p);
+    pc.bias = static_cast<float*>(bb.p);
+    if (hipMemsetAsync(pc.w, 0, (size_t)pc.rows * pc.Ktot * sizeof(float), st) != hipSuccess) return CF_ERR_HIP;
+    if (hipMemsetAsync(pc.bias, 0, pc.rows * sizeof(float), st) != hipSuccess) return CF_ERR_HIP;
+    if (launch_pack_weight(weight, pc.w, Cout, Cin, KH, KW, pc.cin_pad, pc.Ktot, 0, gather ? 1 : 0, nullptr, nullptr, nullptr,
+                           nullptr, 0.f, bias, pc.bias, st) != hipSuccess)
+        return CF_ERR_HIP;
+    ConvParams p;
+    if (gather) {
+        p = gather_conv(pc, in, Cin, H, W, 0, 0, 1.f, 0.f, 0, Ho, Wo, stride, padT, padL, pad_mode, out, Cout, (long)Ho * Wo * Cout, epi);
+    } else {
+        p = nhwc_conv(pc, {{in, Cin, Cin, (long)H * W * Cin}}, Hin, Win, Ho, Wo, stride, padT, padL, pad_mode, out, Cout,
+                      (long)Ho * Wo * Cout, epi);
+        if (a_mode == A_UPS2X) {
+            p.a_mode = A_UPS2X;
+            p.Hsrc = H;
+            p.Wsrc = W;
+        }
+    }
+    hipError_t e = launch_conv(p, B, st, tile);
+    if (e != hipSuccess) return e == hipErrorInvalidValue ? CF_ERR_ARG : CF_ERR_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess) return CF_ERR_HIP;   // temp buffers die here
+    return CF_OK;
+}
+
+extern "C" int cf_op_instance_norm_relu(const float* x, float* out, int B, int C, int H, int W, float eps, void* stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!x || !out || C > 256 || (C % 4) != 0) return CF_ERR_ARG;
+    TmpBuf part, stats;
+    if (hipMalloc(&part.p, sizeof(double) * (size_t)inorm_partial_doubles(B, H * W, C)) != hipSuccess) return CF_ERR_HIP;
+    if (hipMalloc(&stats.p, sizeof(float) * (size_t)B * C * 2) != hipSuccess) return CF_ERR_HIP;
+    const long bs = (long)H * W * C;
+    if (launch_inorm_stats(x, C, bs, B, H * W, C, eps, static_cast<double*>(part.p), static_cast<float*>(stats.p), st) != hipSuccess) return CF_ERR_HIP;
+    if (launch_inorm_apply(x, C, bs, static_cast<float*>(stats.p), nullptr, 0, 0, nullptr, out, C, bs, B, H * W, C, st) != hipSuccess) return CF_ERR_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess) return CF_ERR_HIP;
+    return CF_OK;
+}
+
+extern "C" int cf_op_corr_lookup(const float* fmap1, const float* fmap2, const float* coords, float* out, int B, int D, int hh,
+                                 int ww, void* stream) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!fmap1 || !fmap2 || !coords || !out || (D % 16) != 0 || hh < 8 || ww < 8) return CF_ERR_ARG;
+    const long N = (long)hh * ww;
+    TmpBuf lv[4], feat;
+    int lh[4], lw[4];
+    int a = hh, b = ww;
+    for (int l = 0; l < 4; ++l) {
+        lh[l] = a; lw[l] = b;
+        if (hipMalloc(&lv[l].p, sizeof(float) * (size_t)B * N * a * b) != hipSuccess) return CF_ERR_HIP;
+        a /= 2; b /= 2;
+    }
+    ConvParams p = base_params();
+    p.in[0] = fmap1; p.seg_c[0] = D; p.seg_ld[0] = D; p.seg_bs[0] = N * D; p.nseg = 1;
+    p.Hin = hh; p.Win = ww; p.Hsrc = hh; p.Wsrc = ww; p.Ho = hh; p.Wo = ww;
+    p.KH = 1; p.KW = 1; p.stride = 1; p.a_mode = A_NHWC;
+    p.w = fmap2; p.w_bs = N * D; p.w_rows = (int)N; p.Ktot = D; p.cin_pad = D;
+    p.out = static_cast<float*>(lv[0].p); p.out_ld = (int)N; p.out_bs = N * N; p.cout = (int)N; p.epi = EPI_SCALE;
+    p.scale = 1.0f / sqrtf((float)D);
+    if (launch_conv(p, B, st) != hipSuccess) return CF_ERR_HIP;
+    for (int l = 1; l < 4; ++l)
+        if (launch_corr_pool(static_cast<float*>(lv[l - 1].p), static_cast<float*>(lv[l].p), (long)B * N, lh[l - 1], lw[l - 1], st) != hipSuccess) return CF_ERR_HIP;
+    LookupParams lp;
+    for (int l = 0; l < 4; ++l) { lp.lvl[l] = static_cast<float*>(lv[l].p); lp.lh[l] = lh[l]; lp.lw[l] = lw[l]; }
+    lp.coords1 = coords; lp.out = out; lp.out_ld = 324; lp.motion = nullptr; lp.mo_ld = 0; lp.mo_off = 0;
+    lp.B = B; lp.h8 = hh; lp.w8 = ww; lp.radius = 4; lp.nlevels = 4;
+    if (launch_corr_lookup(lp, st) != hipSuccess) return CF_ERR_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess) return CF_ERR_HIP;
+    return CF_OK;
+}
+
+extern "C" int cf_op_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, void* stream) {
+    return launch_nchw_to_nhwc(src, dst, C, B, C, H * W, static_cast<hipStream_t>(stream)) == hipSuccess ? CF_OK : CF_ERR_HIP;
+}
+extern "C" int cf_op_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, void* stream) {
+    return launch_nhwc_to_nchw(src, C, dst, B, C, H * W, static_cast<hipStream_t>(stream)) == hipSuccess ? CF_OK : CF_ERR_HIP;
+}

@@ -1,0 +1,152 @@
+// cf_kernels.h -- internal launcher interface of libcistaflow (gfx950 only).
+//
+// Data layout in HBM: every activation is fp32 NHWC ("pixel-major"): element
+// (b, y, x, c) lives at  base + b*bs + (y*W + x)*ld + c , where ld >= C lets a
+// producer write straight into a channel slice of a wider concat buffer (so
+// torch.cat never materialises).  Boundary tensors with C <= 5 (event voxel,
+// image, flow) stay planar NCHW exactly as the reference hands them over.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cf {
+
+// ---------------------------------------------------------------------------
+// Implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//   M = output pixels of one image, N = output channels, K = taps * Cin.
+// ---------------------------------------------------------------------------
+enum AMode {
+    A_NHWC = 0,      // up to 3 NHWC channel segments (zero-copy torch.cat)
+    A_UPS2X = 1,     // NHWC source at (Hsrc,Wsrc) read through a fused bilinear x2
+                     // upsample (align_corners=False); conv sees (Hin,Win)=(2Hsrc,2Wsrc)
+    A_GATHER = 2,    // planar NCHW source with tiny Cin: K = taps*Cin flattened
+};
+
+enum Epi {
+    EPI_NONE = 0,            // v = acc + bias
+    EPI_RELU = 1,
+    EPI_SIGMOID = 2,
+    EPI_TANH = 3,
+    EPI_SUB_FROM_AUX = 4,    // out = aux0 - v                         (ISTA: x1 - D(z))
+    EPI_ADD_AUX_SHRINK = 5,  // out = softshrink(v + aux0, lam[n])     (ISTA: P(.) + z)
+    EPI_RELU_ADD_AUX = 6,    // out = relu(v) + aux0                   (EIFusion)
+    EPI_RELU_ADD_AUX_RELU = 7, // out = relu(aux0 + relu(v))           (BN residual block)
+    EPI_LSTC = 8,            // ConvLSTC tail: o = sig(v); c = f*cprev + i*z0; out = o*tanh(c); out2 = c
+    EPI_GRU_ZR = 9,          // n < split: out = sig(v) ; else out2[n-split] = sig(v)*aux0[n-split]
+    EPI_GRU_Q = 10,          // q = tanh(v); out = (1-aux0)*aux1 + aux0*q
+    EPI_TANH_RELU_SPLIT = 11,// n < split: out = tanh(v) ; else out2[n-split] = relu(v)
+    EPI_SCALE = 12,          // out = acc * scale   (no bias)          (all-pairs correlation)
+    EPI_LSTM_ACT = 13,       // n < split: sigmoid ; else tanh         (ConvLSTM gate pre-activation)
+    EPI_ADD_AUX = 14,        // out = v + aux0                         (coords1 += delta_flow)
+};
+
+struct ConvParams {
+    // ---- A operand (activations) ----
+    const float* in[3];
+    int  seg_c[3];      // channels per segment (multiples of 16 in A_NHWC/A_UPS2X)
+    int  seg_ld[3];     // pixel stride in floats
+    long seg_bs[3];     // batch stride in floats
+    int  nseg;
+    int  Hin, Win;      // spatial size the convolution sees
+    int  Hsrc, Wsrc;    // physical source size (A_UPS2X: half res; A_GATHER: un-padded image)
+    int  Ho, Wo;
+    int  KH, KW, stride, padT, padL;
+    int  pad_mode;      // 0 zeros, 1 reflect
+    int  a_mode;
+    // A_GATHER extras: source is [B][g_cin][Hsrc][Wsrc]; the conv's virtual input is that image
+    // shifted by (g_offy,g_offx) (ImagePadder zero pad on top/left), v' = g_scale*v + g_shift
+    // inside the un-padded area, 0 outside.  g_subgrid: subtract the pixel grid (x for c=0,
+    // y for c=1) so that coords1 is read as flow = coords1 - coords0.
+    int   g_cin, g_offy, g_offx, g_subgrid;
+    float g_scale, g_shift;
+    // ---- B operand (packed weights [w_rows][Ktot], K contiguous) ----
+    const float* w;
+    long w_bs;          // batch stride (0 for ordinary weights; N*D for the correlation GEMM)
+    int  w_rows;        // valid rows in the packed matrix
+    int  Ktot;          // taps * cin_pad (A_NHWC/A_UPS2X) or round16(taps*Cin) (A_GATHER)
+    int  cin_pad;       // per-tap K (multiple of 16); unused for A_GATHER
+    const float* bias;  // [>= cout] or nullptr
+    // ---- output ----
+    float* out;  int out_ld;  long out_bs;  int out_cs;   // out[b*bs + m*ld + n*cs]
+    float* out2; int out2_ld; long out2_bs;
+    int  cout;          // store mask: n < cout
+    int  epi;
+    int  split;
+    float scale;
+    const float* aux0; int aux0_ld; long aux0_bs; int aux0_cs;
+    const float* aux1; int aux1_ld; long aux1_bs;
+    const float* aux2; int aux2_ld; long aux2_bs;
+    const float* aux3; int aux3_ld; long aux3_bs;
+    const float* lam;   // [cout] soft-threshold
+};
+
+// tile: 0 auto, else explicit (see conv_igemm.hip)
+hipError_t launch_conv(const ConvParams& p, int batch, hipStream_t s, int tile = 0);
+
+// ---------------------------------------------------------------------------
+// Weight packing (device side, runs once per load_state_dict)
+// ---------------------------------------------------------------------------
+// src: OIHW [Cout][Cin][KH][KW]  ->  dst rows [row0 .. row0+Cout) of [rows][Ktot]
+//   gather==0: k = tap*cin_pad + c ; gather==1: k = tap*Cin + c
+// optional BatchNorm fold (eval): w' = w*g/sqrt(var+eps), b' = (b-mean)*g/sqrt(var+eps)+beta
+hipError_t launch_pack_weight(const float* src, float* dst, int Cout, int Cin, int KH, int KW,
+                              int cin_pad, int Ktot, int row0, int gather,
+                              const float* bn_w, const float* bn_b, const float* bn_mean,
+                              const float* bn_var, float bn_eps,
+                              const float* bias_src, float* bias_dst, hipStream_t s);
+
+// ---------------------------------------------------------------------------
+// HBM-bound kernels
+// ---------------------------------------------------------------------------
+// a4: forward/backward flow warp (grid_sample bilinear, align_corners=True, reflection,
+// x normalised by W not W-1).  img/out: [B][H*W][C] with pixel stride ld.  flow is planar
+// [B][2][Hf][Wf]; when (Hf,Wf) != (H,W) it is first resampled to (H,W) with
+// interpolate(bilinear, align_corners=True) WITHOUT rescaling its values (e2v_model.py:190).
+// flag (nullable): device int; when *flag == 0 the kernel copies img -> out (".any()" false).
+hipError_t launch_warp(const float* img, int img_ld, long img_bs, const float* flow, int Hf, int Wf,
+                       float* out, int out_ld, long out_bs, int B, int C, int H, int W,
+                       int backward, const int* flag, hipStream_t s);
+// flag = any(flow != 0)
+hipError_t launch_any_nonzero(const float* x, long n, int* flag, hipStream_t s);
+
+// InstanceNorm2d(affine=False, eps): two-stage statistics + apply.
+//   stats[b][c] = {mean, rstd}
+hipError_t launch_inorm_stats(const float* x, int ld, long bs, int B, int HW, int C, float eps,
+                              double* partial, float* stats, hipStream_t s);
+// out = relu(norm(x))                                   (res == nullptr)
+// out = relu(res' + relu(norm(x))), res' = res or norm(res) when res_stats != nullptr
+hipError_t launch_inorm_apply(const float* x, int ld, long bs, const float* stats,
+                              const float* res, int res_ld, long res_bs, const float* res_stats,
+                              float* out, int out_ld, long out_bs, int B, int HW, int C, hipStream_t s);
+
+// ConvLSTM cell: g = [px][4*Ch] pre-activated (i,f,o sigmoid | cell tanh)
+hipError_t launch_lstm_cell(const float* g, int g_ld, long g_bs, const float* c_prev, int cp_ld, long cp_bs,
+                            float* h_out, int h_ld, long h_bs, float* c_out, int c_ld, long c_bs,
+                            int B, int HW, int Ch, hipStream_t s);
+
+// correlation pyramid: dst[b][i][y][x] = avg 2x2 of src
+hipError_t launch_corr_pool(const float* src, float* dst, long rows, int Hs, int Ws, hipStream_t s);
+// correlation lookup (a10): out[b][i][lvl*81 + a*9 + bb], channels [324, out_ld) zeroed.
+// also writes flow = coords1 - coords0 into motion[b][i][mo_off + {0,1}] when motion != nullptr.
+struct LookupParams {
+    const float* lvl[4]; int lh[4], lw[4];
+    const float* coords1;       // planar [B][2][h8][w8]
+    float* out; int out_ld;
+    float* motion; int mo_ld; int mo_off;
+    int B, h8, w8, radius, nlevels;
+};
+hipError_t launch_corr_lookup(const LookupParams& p, hipStream_t s);
+
+// coords1 = grid (+ flow_init)
+hipError_t launch_coords_init(float* coords1, const float* flow_init, int B, int h8, int w8, hipStream_t s);
+// flow_up = ds * interpolate(coords1 - coords0, x ds, bilinear, align_corners=True)   (padded, nullable)
+// flow_final = unpad(flow_up)                                                          (nullable)
+// flag (nullable) |= any(flow_final != 0)
+hipError_t launch_upflow(const float* coords1, int B, int h8, int w8, int ds, float* flow_up,
+                         float* flow_final, int H, int W, int padH, int padW, int* flag, hipStream_t s);
+
+// layout helpers for the Python boundary / tests
+hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int dst_ld, int B, int C, int HW, hipStream_t s);
+hipError_t launch_nhwc_to_nchw(const float* src, int src_ld, float* dst, int B, int C, int HW, hipStream_t s);
+
+}  // namespace cf

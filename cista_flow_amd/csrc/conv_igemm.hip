@@ -1,0 +1,533 @@
+// conv_igemm.hip -- implicit-GEMM convolution on the gfx950 fp32 matrix cores.
+//
+// One workgroup (4 waves) owns a BM x BN tile of  out[pixel][cout]  for one image.
+// K runs over (tap, cin) in chunks of 16: the A chunk (BM pixels x 16 channels of the
+// tap-shifted input, reflect/zero padded on the fly) and the B chunk (BN couts x 16) are
+// staged global -> registers -> LDS (double buffered, one barrier per chunk) and consumed
+// with v_mfma_f32_32x32x2_f32 (exact fp32 fma chain, 64 cycles each -> the staging is far
+// off the critical path; the kernel is MFMA-bound by design).
+//
+// LDS image: [row][16 k] with an 80-byte row stride.  A lane reads its row's k = 4h..4h+3
+// (h = lane>>5) of an 8-deep k group with one ds_read_b128; rows r -> 16-byte slot 5r mod 16
+// so every 16-lane group of the b128 read is bank-conflict free.  MFMA step s of a group
+// therefore multiplies k = 8g + 4h + s on both operands -- a permutation of k, which a dot
+// product does not care about.
+//
+// Reference semantics covered (each cited where it is used in cf_api.hip):
+//   nn.Conv2d(padding_mode='reflect'|'zeros', stride 1|2, kernels 1x1,3x3,7x7,1x5,5x1),
+//   F.interpolate(x2, bilinear, align_corners=False)+ReflectionPad2d fused into the A read
+//   (e2v/base_layers.py:195-212), ImagePadder zero pad (utils/image_process.py:87-101) and
+//   `2*image-1` (DCEIFlow/DCEIFlow.py:146) fused into the small-Cin gather read.
+#include "cf_kernels.h"
+
+namespace cf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static constexpr int KC = 16;      // K chunk (floats)
+static constexpr int LDS_S = 20;   // LDS row stride (floats)
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// nn.Conv2d(padding_mode='reflect'): mirror without repeating the edge (pad < size).
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+    i = i < 0 ? -i : i;
+    i = i >= n ? 2 * (n - 1) - i : i;
+    return i;
+}
+
+__device__ __forceinline__ const float* sel3(const float* const (&a)[3], int s) {
+    return s == 0 ? a[0] : (s == 1 ? a[1] : a[2]);
+}
+
+
+static constexpr int EPI_S = 36;   // per-wave epilogue patch row stride (floats)
+
+// Element-wise tail of one conv output quad: pixel m, couts n..n+3 (n % 4 == 0).
+__device__ __forceinline__ void epilogue4(const ConvParams& p, int b, int m, int n, f32x4 acc) {
+    const int nv = (p.cout - n) < 4 ? (p.cout - n) : 4;      // valid couts in this quad
+    const bool full = nv == 4;
+    f32x4 v = acc;
+    if (p.bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (e < nv) ? p.bias[n + e] : 0.f;
+    }
+    const long ooff = (long)b * p.out_bs + (long)m * p.out_ld + (long)n * p.out_cs;
+    const bool ovec = full && p.out_cs == 1 && ((ooff & 3) == 0);
+    f32x4 o = v;
+    bool to_out = true;   // false: result goes to out2 (split epilogues)
+    switch (p.epi) {
+        case EPI_NONE: break;
+        case EPI_RELU:
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fmaxf(v[e], 0.f);
+            break;
+        case EPI_SIGMOID:
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = sigmoidf_(v[e]);
+            break;
+        case EPI_TANH:
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = tanhf(v[e]);
+            break;
+        case EPI_SUB_FROM_AUX: {
+            const long off = (long)b * p.aux0_bs + (long)m * p.aux0_ld + n;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = p.aux0[off + (e < nv ? e : 0)] - v[e];
+        } break;
+        case EPI_ADD_AUX_SHRINK: {
+            const long off = (long)b * p.aux0_bs + (long)m * p.aux0_ld + n;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ee = e < nv ? e : 0;
+                const float x = v[e] + p.aux0[off + ee];
+                const float l = p.lam[n + ee];
+                o[e] = fmaxf(x - l, 0.f) - fmaxf(-x - l, 0.f);
+            }
+        } break;
+        case EPI_RELU_ADD_AUX: {
+            const long off = (long)b * p.aux0_bs + (long)m * p.aux0_ld + n;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fmaxf(v[e], 0.f) + p.aux0[off + (e < nv ? e : 0)];
+        } break;
+        case EPI_RELU_ADD_AUX_RELU: {
+            const long off = (long)b * p.aux0_bs + (long)m * p.aux0_ld + n;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fmaxf(p.aux0[off + (e < nv ? e : 0)] + fmaxf(v[e], 0.f), 0.f);
+        } break;
+        case EPI_LSTC: {
+            // aux0 = sigmoid gates [px][2*split] (i | f), aux1 = z0, aux2 = c_prev; out = z, out2 = c
+            const long o0 = (long)b * p.aux0_bs + (long)m * p.aux0_ld + n;
+            const long o1 = (long)b * p.aux1_bs + (long)m * p.aux1_ld + n;
+            const long o2 = (long)b * p.aux2_bs + (long)m * p.aux2_ld + n;
+            const long oc = (long)b * p.out2_bs + (long)m * p.out2_ld + n;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (e < nv) {
+                    const float ig = p.aux0[o0 + e];
+                    const float fg = p.aux0[o0 + p.split + e];
+                    const float z0 = p.aux1[o1 + e];
+                    const float cp = p.aux2[o2 + e];
+                    const float og = sigmoidf_(v[e]);
+                    const float c = fg * cp + ig * z0;
+                    o[e] = og * tanhf(c);
+                    p.out2[oc + e] = c;
+                }
+            }
+        } break;
+        case EPI_GRU_ZR: {
+            // split % 4 == 0, so a quad never straddles the z | r boundary
+            if (n < p.split) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = sigmoidf_(v[e]);
+            } else {
+                to_out = false;
+                const int nn = n - p.split;
+                const long oh = (long)b * p.aux0_bs + (long)m * p.aux0_ld + nn;
+                const long o2 = (long)b * p.out2_bs + (long)m * p.out2_ld + nn;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < nv) p.out2[o2 + e] = sigmoidf_(v[e]) * p.aux0[oh + e];
+            }
+        } break;
+        case EPI_GRU_Q: {
+            const long oz = (long)b * p.aux0_bs + (long)m * p.aux0_ld + n;
+            const long oh = (long)b * p.aux1_bs + (long)m * p.aux1_ld + n;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ee = e < nv ? e : 0;
+                const float z = p.aux0[oz + ee];
+                const float h = p.aux1[oh + ee];
+                o[e] = (1.f - z) * h + z * tanhf(v[e]);
+            }
+        } break;
+        case EPI_TANH_RELU_SPLIT: {
+            if (n < p.split) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = tanhf(v[e]);
+            } else {
+                to_out = false;
+                const long o2 = (long)b * p.out2_bs + (long)m * p.out2_ld + (n - p.split);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < nv) p.out2[o2 + e] = fmaxf(v[e], 0.f);
+            }
+        } break;
+        case EPI_SCALE:
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = acc[e] * p.scale;
+            break;
+        case EPI_LSTM_ACT:
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (n < p.split) ? sigmoidf_(v[e]) : tanhf(v[e]);
+            break;
+        case EPI_ADD_AUX: {
+            const long off = (long)b * p.aux0_bs + (long)m * p.aux0_ld + (long)n * p.aux0_cs;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = v[e] + p.aux0[off + (long)(e < nv ? e : 0) * p.aux0_cs];
+        } break;
+        default: break;
+    }
+    if (to_out) {
+        if (ovec) {
+            *reinterpret_cast<f32x4*>(p.out + ooff) = o;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (e < nv) p.out[ooff + (long)e * p.out_cs] = o[e];
+        }
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    static_assert(BM % 64 == 0, "BM multiple of 64");
+    constexpr int TM = BM / (32 * WAVES_M);
+    constexpr int TN = BN / (32 * WAVES_N);
+    constexpr int A_IT = BM / 64;
+    constexpr int B_IT = (BN * 4 + 255) / 256;
+    constexpr int STAGE = (BM + BN) * LDS_S;
+
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WAVES_N;
+    const int wn = wave % WAVES_N;
+    const int b = blockIdx.z;
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int M = p.Ho * p.Wo;
+    const int q = tid & 3;
+    const int rbase = tid >> 2;
+
+    int a_oy[A_IT], a_ox[A_IT];
+    bool a_ok[A_IT];
+#pragma unroll
+    for (int j = 0; j < A_IT; ++j) {
+        const int m = m0 + rbase + 64 * j;
+        a_ok[j] = m < M;
+        const int oy = m / p.Wo;
+        a_oy[j] = oy;
+        a_ox[j] = m - oy * p.Wo;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nck = p.Ktot / KC;
+    const int cpt = (p.a_mode == A_GATHER) ? 1 : p.cin_pad / KC;  // chunks per tap
+    const float* wbase = p.w + (long)b * p.w_bs;
+
+    f32x4 a_reg[A_IT], b_reg[B_IT];
+
+    auto load_chunk = [&](int ck) {
+        // ---- B: packed weights, K contiguous ----
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const int slot = tid + 256 * it;
+            const int row = slot >> 2;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row < BN && (n0 + row) < p.w_rows)
+                v = *reinterpret_cast<const f32x4*>(wbase + (long)(n0 + row) * p.Ktot + ck * KC + q * 4);
+            b_reg[it] = v;
+        }
+        // ---- A ----
+        if (p.a_mode == A_GATHER) {
+            const float* src = p.in[0] + (long)b * p.seg_bs[0];
+            const int ntap = p.KH * p.KW;
+#pragma unroll
+            for (int j = 0; j < A_IT; ++j) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int kk = ck * KC + q * 4 + e;
+                    const int tap = kk / p.g_cin;
+                    const int c = kk - tap * p.g_cin;
+                    const int ky = tap / p.KW;
+                    const int kx = tap - ky * p.KW;
+                    int iy = a_oy[j] * p.stride + ky - p.padT;
+                    int ix = a_ox[j] * p.stride + kx - p.padL;
+                    bool ok = a_ok[j] && tap < ntap;
+                    if (p.pad_mode == 1) {
+                        iy = reflect_idx(iy, p.Hin);
+                        ix = reflect_idx(ix, p.Win);
+                    } else {
+                        ok = ok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+                    }
+                    const int sy = iy - p.g_offy;
+                    const int sx = ix - p.g_offx;
+                    ok = ok && sy >= 0 && sx >= 0;
+                    float x = 0.f;
+                    if (ok) {
+                        x = src[((long)c * p.Hsrc + sy) * p.Wsrc + sx];
+                        x = x * p.g_scale + p.g_shift;
+                        if (p.g_subgrid) x -= (c == 0) ? (float)sx : (float)sy;
+                    }
+                    v[e] = x;
+                }
+                a_reg[j] = v;
+            }
+        } else {
+            const int tap = ck / cpt;
+            int cc = (ck - tap * cpt) * KC;
+            const int ky = tap / p.KW;
+            const int kx = tap - ky * p.KW;
+            int s = 0;
+            while (s < p.nseg - 1 && cc >= p.seg_c[s]) {
+                cc -= p.seg_c[s];
+                ++s;
+            }
+            const float* src = sel3(p.in, s) + (long)b * (s == 0 ? p.seg_bs[0] : (s == 1 ? p.seg_bs[1] : p.seg_bs[2]));
+            const int ld = s == 0 ? p.seg_ld[0] : (s == 1 ? p.seg_ld[1] : p.seg_ld[2]);
+            const int coff = cc + q * 4;
+            if (p.a_mode == A_NHWC) {
+#pragma unroll
+                for (int j = 0; j < A_IT; ++j) {
+                    int iy = a_oy[j] * p.stride + ky - p.padT;
+                    int ix = a_ox[j] * p.stride + kx - p.padL;
+                    bool ok = a_ok[j];
+                    if (p.pad_mode == 1) {
+                        iy = reflect_idx(iy, p.Hin);
+                        ix = reflect_idx(ix, p.Win);
+                    } else {
+                        ok = ok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+                    }
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (ok) v = *reinterpret_cast<const f32x4*>(src + ((long)iy * p.Win + ix) * ld + coff);
+                    a_reg[j] = v;
+                }
+            } else {  // A_UPS2X: bilinear x2 (align_corners=False) of the (Hsrc,Wsrc) source
+#pragma unroll
+                for (int j = 0; j < A_IT; ++j) {
+                    int uy = a_oy[j] * p.stride + ky - p.padT;
+                    int ux = a_ox[j] * p.stride + kx - p.padL;
+                    bool ok = a_ok[j];
+                    if (p.pad_mode == 1) {
+                        uy = reflect_idx(uy, p.Hin);
+                        ux = reflect_idx(ux, p.Win);
+                    } else {
+                        ok = ok && uy >= 0 && uy < p.Hin && ux >= 0 && ux < p.Win;
+                    }
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (ok) {
+                        float sy = ((float)uy + 0.5f) * 0.5f - 0.5f;
+                        float sx = ((float)ux + 0.5f) * 0.5f - 0.5f;
+                        sy = sy < 0.f ? 0.f : sy;
+                        sx = sx < 0.f ? 0.f : sx;
+                        const int y0 = (int)sy, x0 = (int)sx;
+                        const int y1 = y0 + (y0 < p.Hsrc - 1 ? 1 : 0);
+                        const int x1 = x0 + (x0 < p.Wsrc - 1 ? 1 : 0);
+                        const float ly1 = sy - (float)y0, lx1 = sx - (float)x0;
+                        const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+                        const f32x4 v00 = *reinterpret_cast<const f32x4*>(src + ((long)y0 * p.Wsrc + x0) * ld + coff);
+                        const f32x4 v01 = *reinterpret_cast<const f32x4*>(src + ((long)y0 * p.Wsrc + x1) * ld + coff);
+                        const f32x4 v10 = *reinterpret_cast<const f32x4*>(src + ((long)y1 * p.Wsrc + x0) * ld + coff);
+                        const f32x4 v11 = *reinterpret_cast<const f32x4*>(src + ((long)y1 * p.Wsrc + x1) * ld + coff);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            v[e] = ly0 * (lx0 * v00[e] + lx1 * v01[e]) + ly1 * (lx0 * v10[e] + lx1 * v11[e]);
+                    }
+                    a_reg[j] = v;
+                }
+            }
+        }
+    };
+
+    auto store_chunk = [&](int buf) {
+        float* sA = smem + buf * STAGE;
+        float* sB = sA + BM * LDS_S;
+#pragma unroll
+        for (int j = 0; j < A_IT; ++j)
+            *reinterpret_cast<f32x4*>(sA + (rbase + 64 * j) * LDS_S + q * 4) = a_reg[j];
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const int slot = tid + 256 * it;
+            const int row = slot >> 2;
+            if (row < BN) *reinterpret_cast<f32x4*>(sB + row * LDS_S + q * 4) = b_reg[it];
+        }
+    };
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+
+    const int lr = lane & 31;
+    const int lh = lane >> 5;
+    for (int ck = 0; ck < nck; ++ck) {
+        const int buf = ck & 1;
+        if (ck + 1 < nck) load_chunk(ck + 1);
+        const float* sA = smem + buf * STAGE;
+        const float* sB = sA + BM * LDS_S;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = *reinterpret_cast<const f32x4*>(sA + ((wm * TM + i) * 32 + lr) * LDS_S + ks * 8 + lh * 4);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bf[j] = *reinterpret_cast<const f32x4*>(sB + ((wn * TN + j) * 32 + lr) * LDS_S + ks * 8 + lh * 4);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        }
+        if (ck + 1 < nck) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ----
+    // C/D map of the 32x32 MFMA: col = lane&31 (cout), row = (r&3)+8*(r>>2)+4*(lane>>5).  Each
+    // 32x32 sub-tile goes through a per-wave LDS patch so that a lane ends up with 4 consecutive
+    // couts of one pixel: aux reads and the store are then 16-byte accesses on 128-byte rows.
+    float* sW = smem + wave * (32 * EPI_S);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                sW[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_S + lr] = acc[i][j][r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int nb = n0 + (wn * TN + j) * 32 + (lane & 7) * 4;
+            const int mb = m0 + (wm * TM + i) * 32 + (lane >> 3);
+#pragma unroll 1
+            for (int it = 0; it < 4; ++it) {
+                const int m = mb + it * 8;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(sW + ((lane >> 3) + it * 8) * EPI_S + (lane & 7) * 4);
+                if (m < M && nb < p.cout) epilogue4(p, b, m, nb, v);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static hipError_t launch_t(const ConvParams& p, int batch, hipStream_t s) {
+    const int M = p.Ho * p.Wo;
+    dim3 grid((M + BM - 1) / BM, (p.cout + BN - 1) / BN, batch);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// tile ids: 1 = 128x128, 2 = 128x64, 3 = 128x96, 4 = 64x64, 5 = 64x128, 6 = 128x32
+hipError_t launch_conv(const ConvParams& p, int batch, hipStream_t s, int tile) {
+    // ---- host-side shape checks: a bad descriptor must never reach the GPU ----
+    if (p.Ktot <= 0 || (p.Ktot % KC) != 0 || p.cout <= 0 || batch <= 0 || p.Ho <= 0 || p.Wo <= 0)
+        return hipErrorInvalidValue;
+    if (!p.out || !p.w || !p.in[0]) return hipErrorInvalidValue;
+    if (p.a_mode == A_GATHER) {
+        if (p.g_cin <= 0 || p.Ktot < p.KH * p.KW * p.g_cin) return hipErrorInvalidValue;
+        if (p.Hin != p.Hsrc + p.g_offy || p.Win != p.Wsrc + p.g_offx) return hipErrorInvalidValue;
+    } else {
+        if (p.cin_pad <= 0 || (p.cin_pad % KC) != 0 || p.Ktot != p.KH * p.KW * p.cin_pad)
+            return hipErrorInvalidValue;
+        int sum = 0;
+        if (p.nseg < 1 || p.nseg > 3) return hipErrorInvalidValue;
+        for (int i = 0; i < p.nseg; ++i) {
+            if (!p.in[i] || (p.seg_c[i] % KC) != 0 || (p.seg_ld[i] % 4) != 0 || p.seg_ld[i] < p.seg_c[i])
+                return hipErrorInvalidValue;
+            if ((reinterpret_cast<uintptr_t>(p.in[i]) & 15) != 0) return hipErrorInvalidValue;
+            sum += p.seg_c[i];
+        }
+        if (sum != p.cin_pad) return hipErrorInvalidValue;
+        if (p.a_mode == A_UPS2X && (p.Hin != 2 * p.Hsrc || p.Win != 2 * p.Wsrc)) return hipErrorInvalidValue;
+        if (p.a_mode == A_NHWC && (p.Hin != p.Hsrc || p.Win != p.Wsrc)) return hipErrorInvalidValue;
+    }
+    if (p.pad_mode == 1 && (p.padT >= p.Hin || p.padL >= p.Win || p.KH - 1 - p.padT >= p.Hin || p.KW - 1 - p.padL >= p.Win))
+        return hipErrorInvalidValue;
+    if ((reinterpret_cast<uintptr_t>(p.w) & 15) != 0) return hipErrorInvalidValue;
+    if (p.w_rows < p.cout) return hipErrorInvalidValue;
+    // the last input row/col a valid output touches must exist (stride/pad consistency)
+    if ((p.Ho - 1) * p.stride - p.padT + 0 >= p.Hin || (p.Wo - 1) * p.stride - p.padL >= p.Win)
+        return hipErrorInvalidValue;
+
+    if (tile == 0) {
+        const int M = p.Ho * p.Wo;
+        int bn;
+        if (p.cout <= 32) bn = 32;
+        else if (p.cout <= 64) bn = 64;
+        else if ((p.cout % 96) == 0 && (p.cout % 128) != 0) bn = 96;
+        else bn = 128;
+        const long wg128 = (long)((M + 127) / 128) * ((p.cout + bn - 1) / bn) * batch;
+        if (bn == 32) tile = 6;
+        else if (bn == 96) tile = 3;
+        else if (bn == 64) tile = (wg128 >= 512) ? 2 : 4;
+        else tile = (wg128 >= 512) ? 1 : ((long)((M + 63) / 64) * ((p.cout + 127) / 128) * batch >= 512 ? 5 : 4);
+    }
+    switch (tile) {
+        case 1: return launch_t<128, 128, 2, 2>(p, batch, s);
+        case 2: return launch_t<128, 64, 2, 2>(p, batch, s);
+        case 3: return launch_t<128, 96, 4, 1>(p, batch, s);
+        case 4: return launch_t<64, 64, 2, 2>(p, batch, s);
+        case 5: return launch_t<64, 128, 2, 2>(p, batch, s);
+        case 6: return launch_t<128, 32, 4, 1>(p, batch, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// weight packing
+// ---------------------------------------------------------------------------
+__global__ void pack_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int Cin,
+                                   int KH, int KW, int cin_pad, int Ktot, int row0, int gather,
+                                   const float* bn_w, const float* bn_b, const float* bn_mean,
+                                   const float* bn_var, float bn_eps, const float* bias_src, float* bias_dst) {
+    const long total = (long)Cout * Cin * KH * KW;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < total) {
+        const int kw = idx % KW;
+        long t = idx / KW;
+        const int kh = t % KH;
+        t /= KH;
+        const int c = t % Cin;
+        const int o = (int)(t / Cin);
+        float v = src[idx];
+        if (bn_var) v *= bn_w[o] / sqrtf(bn_var[o] + bn_eps);
+        const int tap = kh * KW + kw;
+        const long k = gather ? ((long)tap * Cin + c) : ((long)tap * cin_pad + c);
+        dst[(long)(row0 + o) * Ktot + k] = v;
+    }
+    if (idx < Cout && bias_dst) {
+        const int o = (int)idx;
+        float bv = bias_src ? bias_src[o] : 0.f;
+        if (bn_var) bv = (bv - bn_mean[o]) * (bn_w[o] / sqrtf(bn_var[o] + bn_eps)) + bn_b[o];
+        bias_dst[row0 + o] = bv;
+    }
+}
+
+hipError_t launch_pack_weight(const float* src, float* dst, int Cout, int Cin, int KH, int KW, int cin_pad,
+                              int Ktot, int row0, int gather, const float* bn_w, const float* bn_b,
+                              const float* bn_mean, const float* bn_var, float bn_eps, const float* bias_src,
+                              float* bias_dst, hipStream_t s) {
+    const long total = (long)Cout * Cin * KH * KW;
+    if (total <= 0) return hipErrorInvalidValue;
+    if (gather) {
+        if (Ktot < KH * KW * Cin) return hipErrorInvalidValue;
+    } else {
+        if (cin_pad < Cin || Ktot != KH * KW * cin_pad) return hipErrorInvalidValue;
+    }
+    const int threads = 256;
+    const long blocks = (total + threads - 1) / threads;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)blocks), dim3(threads), 0, s, src, dst, Cout, Cin, KH, KW,
+                       cin_pad, Ktot, row0, gather, bn_w, bn_b, bn_mean, bn_var, bn_eps, bias_src, bias_dst);
+    return hipGetLastError();
+}
+
+}  // namespace cf

@@ -1,0 +1,542 @@
+// pointwise.hip -- the HBM-bound kernels of the CISTA-Flow hot path (gfx950).
+//
+// Everything here moves each byte once: flow warp (bilinear gather), instance-norm
+// statistics / apply, ConvLSTM cell, correlation pyramid + lookup, flow up-sampling and the
+// NCHW<->NHWC boundary shuffles.  NHWC tensors are addressed as  base + b*bs + pixel*ld + c.
+#include "cf_kernels.h"
+
+namespace cf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------
+// grid_sample coordinate helpers -- restated from ATen's CPU grid sampler
+// (align_corners=True): unnormalize = (g + 1) * ((size-1)/2); reflection about
+// [0, size-1]:  extra = |x| - trunc(|x| / (2*span)) * 2*span ; min(extra, 2*span - extra).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float reflect_coord(float x, int size) {
+    if (size <= 1) return 0.f;
+    const float twice_span = (float)(size - 1) * 2.f;
+    const float a = fabsf(x);
+    const float flips = truncf(a / twice_span);
+    const float extra = a - flips * twice_span;
+    return fminf(extra, twice_span - extra);
+}
+
+// interpolate(..., mode='bilinear', align_corners=True) source index for output index d
+__device__ __forceinline__ void ac_true_src(int d, int in, int out, int& i0, int& i1, float& l0, float& l1) {
+    const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    const float src = scale * (float)d;
+    i0 = (int)src;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+    l0 = 1.f - l1;
+}
+
+// flow value at (b, ch, y, x) of a (H,W) grid, resampled from planar [B][2][Hf][Wf]
+__device__ __forceinline__ float flow_at(const float* flow, int b, int ch, int y, int x, int H, int W, int Hf, int Wf) {
+    const float* f = flow + ((long)b * 2 + ch) * Hf * Wf;
+    if (Hf == H && Wf == W) return f[(long)y * Wf + x];
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    ac_true_src(y, Hf, H, y0, y1, ly0, ly1);
+    ac_true_src(x, Wf, W, x0, x1, lx0, lx1);
+    const float v00 = f[(long)y0 * Wf + x0], v01 = f[(long)y0 * Wf + x1];
+    const float v10 = f[(long)y1 * Wf + x0], v11 = f[(long)y1 * Wf + x1];
+    return ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+}
+
+// ---------------------------------------------------------------------------
+// a4: flow warp.  utils/flow_utils.py:153-190 (forward: x - u) / :83-120 (backward: x + u);
+// grid = 2*(xs/W - 0.5) with W, not W-1, then grid_sample(bilinear, align_corners=True,
+// padding_mode='reflection').  One thread = one pixel x 4 channels (16-byte accesses).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ img, int img_ld, long img_bs,
+                                                   const float* __restrict__ flow, int Hf, int Wf,
+                                                   float* __restrict__ out, int out_ld, long out_bs, int B, int C,
+                                                   int H, int W, int backward, const int* flag, int cq /*quads per px*/,
+                                                   int vec) {
+    const long total = (long)B * H * W * cq;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int qd = (int)(gid % cq);
+    const long pix = gid / cq;
+    const int x = (int)(pix % W);
+    const int y = (int)((pix / W) % H);
+    const int b = (int)(pix / ((long)W * H));
+    const int c0 = qd * 4;
+    const float* ib = img + (long)b * img_bs;
+    float* ob = out + (long)b * out_bs + ((long)y * W + x) * out_ld + c0;
+
+    const bool passthrough = flag && (*flag == 0);
+    if (passthrough) {
+        const float* src = ib + ((long)y * W + x) * img_ld + c0;
+        if (vec) {
+            *reinterpret_cast<f32x4*>(ob) = *reinterpret_cast<const f32x4*>(src);
+        } else {
+            for (int e = 0; e < 4 && c0 + e < C; ++e) ob[e] = src[e];
+        }
+        return;
+    }
+    const float u = flow_at(flow, b, 0, y, x, H, W, Hf, Wf);
+    const float v = flow_at(flow, b, 1, y, x, H, W, Hf, Wf);
+    float xs = backward ? ((float)x + u) : ((float)x - u);
+    float ys = backward ? ((float)y + v) : ((float)y - v);
+    xs = 2.f * (xs / (float)W - 0.5f);
+    ys = 2.f * (ys / (float)H - 0.5f);
+    float ix = (xs + 1.f) * ((float)(W - 1) / 2.f);
+    float iy = (ys + 1.f) * ((float)(H - 1) / 2.f);
+    ix = reflect_coord(ix, W);
+    iy = reflect_coord(iy, H);
+    // clip (ATen clips after reflecting)
+    ix = fminf(fmaxf(ix, 0.f), (float)(W - 1));
+    iy = fminf(fmaxf(iy, 0.f), (float)(H - 1));
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const int x1 = x0 + 1, y1 = y0 + 1;
+    const float tx = ix - fx, ty = iy - fy;   // ATen: w = x - x_w ; e = 1 - w
+    const float wx0 = 1.f - tx, wy0 = 1.f - ty;
+    const float w00 = wy0 * wx0, w01 = wy0 * tx, w10 = ty * wx0, w11 = ty * tx;
+    const bool x1ok = x1 <= W - 1, y1ok = y1 <= H - 1;   // x0,y0 always in range after the clip
+    const float* p00 = ib + ((long)y0 * W + x0) * img_ld + c0;
+    const float* p01 = ib + ((long)y0 * W + (x1ok ? x1 : x0)) * img_ld + c0;
+    const float* p10 = ib + ((long)(y1ok ? y1 : y0) * W + x0) * img_ld + c0;
+    const float* p11 = ib + ((long)(y1ok ? y1 : y0) * W + (x1ok ? x1 : x0)) * img_ld + c0;
+    const float m01 = x1ok ? 1.f : 0.f, m10 = y1ok ? 1.f : 0.f, m11 = (x1ok && y1ok) ? 1.f : 0.f;
+    if (vec) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p00);
+        const f32x4 bq = *reinterpret_cast<const f32x4*>(p01);
+        const f32x4 cqv = *reinterpret_cast<const f32x4*>(p10);
+        const f32x4 d = *reinterpret_cast<const f32x4*>(p11);
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            r[e] = a[e] * w00 + (bq[e] * m01) * w01 + (cqv[e] * m10) * w10 + (d[e] * m11) * w11;
+        *reinterpret_cast<f32x4*>(ob) = r;
+    } else {
+        for (int e = 0; e < 4 && c0 + e < C; ++e)
+            ob[e] = p00[e] * w00 + (p01[e] * m01) * w01 + (p10[e] * m10) * w10 + (p11[e] * m11) * w11;
+    }
+}
+
+hipError_t launch_warp(const float* img, int img_ld, long img_bs, const float* flow, int Hf, int Wf, float* out,
+                       int out_ld, long out_bs, int B, int C, int H, int W, int backward, const int* flag,
+                       hipStream_t s) {
+    if (!img || !flow || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0 || Hf <= 0 || Wf <= 0) return hipErrorInvalidValue;
+    if (img_ld < C || out_ld < C) return hipErrorInvalidValue;
+    const int cq = (C + 3) / 4;
+    const int vec = ((C % 4) == 0 && (img_ld % 4) == 0 && (out_ld % 4) == 0 && (img_bs % 4) == 0 && (out_bs % 4) == 0 &&
+                     (reinterpret_cast<uintptr_t>(img) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0)
+                        ? 1
+                        : 0;
+    const long total = (long)B * H * W * cq;
+    const long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(warp_kernel, dim3((unsigned)blocks), dim3(256), 0, s, img, img_ld, img_bs, flow, Hf, Wf, out,
+                       out_ld, out_bs, B, C, H, W, backward, flag, cq, vec);
+    return hipGetLastError();
+}
+
+// flag |= any(x != 0)   (NaN != 0 is true, like torch.Tensor.any on floats)
+__global__ void any_nonzero_kernel(const float* __restrict__ x, long n, int* flag) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    bool nz = false;
+    for (; i < n; i += stride) nz = nz || (x[i] != 0.0f);
+    if (__any(nz)) {
+        if ((threadIdx.x & 63) == 0) *flag = 1;
+    }
+}
+
+hipError_t launch_any_nonzero(const float* x, long n, int* flag, hipStream_t s) {
+    if (!x || !flag || n <= 0) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), s);
+    if (e != hipSuccess) return e;
+    long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(any_nonzero_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n, flag);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// InstanceNorm2d (affine=False, biased variance, eps) -- raft_encoder.py:32-36,136-137.
+// stage 1: per (image, pixel-chunk) partial {sum, sum of squares} in fp64 for every channel
+// stage 2: fold the chunks -> {mean, rstd}
+// ---------------------------------------------------------------------------
+static constexpr int IN_CHUNK = 512;   // pixels per stage-1 workgroup
+
+__global__ __launch_bounds__(256) void inorm_partial_kernel(const float* __restrict__ x, int ld, long bs, int HW, int C,
+                                                            double* __restrict__ partial, int nchunk) {
+    __shared__ double sh[2 * 256];
+    const int b = blockIdx.y, ch = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int tpc = 256 / C >= 1 ? 256 / C : 1;   // pixel lanes per channel (C <= 256)
+    const int c = tid % C;
+    const int pl = tid / C;
+    double s = 0.0, ss = 0.0;
+    if (pl < tpc) {
+        const int p0 = ch * IN_CHUNK;
+        const int p1 = min(HW, p0 + IN_CHUNK);
+        const float* xb = x + (long)b * bs;
+        for (int p = p0 + pl; p < p1; p += tpc) {
+            const double v = (double)xb[(long)p * ld + c];
+            s += v;
+            ss += v * v;
+        }
+    }
+    sh[tid] = s;
+    sh[256 + tid] = ss;
+    __syncthreads();
+    if (tid < C) {
+        double a = 0.0, aa = 0.0;
+        for (int k = 0; k < tpc; ++k) {
+            a += sh[k * C + tid];
+            aa += sh[256 + k * C + tid];
+        }
+        double* dst = partial + (((long)b * nchunk + ch) * C + tid) * 2;
+        dst[0] = a;
+        dst[1] = aa;
+    }
+}
+
+__global__ void inorm_final_kernel(const double* __restrict__ partial, int nchunk, int C, int HW, float eps,
+                                   float* __restrict__ stats, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i % C;
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+        const double* src = partial + (((long)b * nchunk + k) * C + c) * 2;
+        s += src[0];
+        ss += src[1];
+    }
+    const double mean = s / (double)HW;
+    double var = ss / (double)HW - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[(long)i * 2 + 0] = (float)mean;
+    stats[(long)i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+hipError_t launch_inorm_stats(const float* x, int ld, long bs, int B, int HW, int C, float eps, double* partial,
+                              float* stats, hipStream_t s) {
+    if (!x || !partial || !stats || C <= 0 || C > 256 || B <= 0 || HW <= 0 || ld < C) return hipErrorInvalidValue;
+    const int nchunk = (HW + IN_CHUNK - 1) / IN_CHUNK;
+    hipLaunchKernelGGL(inorm_partial_kernel, dim3(nchunk, B), dim3(256), 0, s, x, ld, bs, HW, C, partial, nchunk);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(inorm_final_kernel, dim3((B * C + 255) / 256), dim3(256), 0, s, partial, nchunk, C, HW, eps, stats,
+                       B);
+    return hipGetLastError();
+}
+
+// number of doubles launch_inorm_stats needs in `partial`
+long inorm_partial_doubles(int B, int HW, int C) { return (long)B * ((HW + IN_CHUNK - 1) / IN_CHUNK) * C * 2; }
+
+__global__ __launch_bounds__(256) void inorm_apply_kernel(const float* __restrict__ x, int ld, long bs,
+                                                          const float* __restrict__ stats, const float* __restrict__ res,
+                                                          int res_ld, long res_bs, const float* __restrict__ res_stats,
+                                                          float* __restrict__ out, int out_ld, long out_bs, int B, int HW,
+                                                          int C) {
+    const int cq = C / 4;
+    const long total = (long)B * HW * cq;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int c0 = (int)(gid % cq) * 4;
+    const long pix = gid / cq;
+    const int p = (int)(pix % HW);
+    const int b = (int)(pix / HW);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + (long)b * bs + (long)p * ld + c0);
+    f32x4 r;
+    const float* st = stats + ((long)b * C + c0) * 2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = fmaxf((v[e] - st[2 * e]) * st[2 * e + 1], 0.f);
+    if (res) {
+        f32x4 rv = *reinterpret_cast<const f32x4*>(res + (long)b * res_bs + (long)p * res_ld + c0);
+        if (res_stats) {
+            const float* rs = res_stats + ((long)b * C + c0) * 2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rv[e] = (rv[e] - rs[2 * e]) * rs[2 * e + 1];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = fmaxf(rv[e] + r[e], 0.f);
+    }
+    *reinterpret_cast<f32x4*>(out + (long)b * out_bs + (long)p * out_ld + c0) = r;
+}
+
+hipError_t launch_inorm_apply(const float* x, int ld, long bs, const float* stats, const float* res, int res_ld,
+                              long res_bs, const float* res_stats, float* out, int out_ld, long out_bs, int B, int HW,
+                              int C, hipStream_t s) {
+    if (!x || !stats || !out || (C % 4) != 0 || (ld % 4) != 0 || (out_ld % 4) != 0 || (bs % 4) != 0 || (out_bs % 4) != 0)
+        return hipErrorInvalidValue;
+    if (res && ((res_ld % 4) != 0 || (res_bs % 4) != 0)) return hipErrorInvalidValue;
+    const long total = (long)B * HW * (C / 4);
+    hipLaunchKernelGGL(inorm_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, ld, bs, stats, res,
+                       res_ld, res_bs, res_stats, out, out_ld, out_bs, B, HW, C);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// ConvLSTM cell (e2v/base_layers.py:117-132): gates arrive activated from the conv epilogue
+// in chunk order  in | remember | out | cell.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict__ g, int g_ld, long g_bs,
+                                                        const float* __restrict__ c_prev, int cp_ld, long cp_bs,
+                                                        float* __restrict__ h_out, int h_ld, long h_bs,
+                                                        float* __restrict__ c_out, int c_ld, long c_bs, int B, int HW,
+                                                        int Ch) {
+    const int cq = Ch / 4;
+    const long total = (long)B * HW * cq;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int c0 = (int)(gid % cq) * 4;
+    const long pix = gid / cq;
+    const int p = (int)(pix % HW);
+    const int b = (int)(pix / HW);
+    const float* gp = g + (long)b * g_bs + (long)p * g_ld + c0;
+    const f32x4 ig = *reinterpret_cast<const f32x4*>(gp);
+    const f32x4 fg = *reinterpret_cast<const f32x4*>(gp + Ch);
+    const f32x4 og = *reinterpret_cast<const f32x4*>(gp + 2 * Ch);
+    const f32x4 cg = *reinterpret_cast<const f32x4*>(gp + 3 * Ch);
+    f32x4 cp = {0.f, 0.f, 0.f, 0.f};
+    if (c_prev) cp = *reinterpret_cast<const f32x4*>(c_prev + (long)b * cp_bs + (long)p * cp_ld + c0);
+    f32x4 c, h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        c[e] = fg[e] * cp[e] + ig[e] * cg[e];
+        h[e] = og[e] * tanhf(c[e]);
+    }
+    *reinterpret_cast<f32x4*>(c_out + (long)b * c_bs + (long)p * c_ld + c0) = c;
+    *reinterpret_cast<f32x4*>(h_out + (long)b * h_bs + (long)p * h_ld + c0) = h;
+}
+
+hipError_t launch_lstm_cell(const float* g, int g_ld, long g_bs, const float* c_prev, int cp_ld, long cp_bs,
+                            float* h_out, int h_ld, long h_bs, float* c_out, int c_ld, long c_bs, int B, int HW, int Ch,
+                            hipStream_t s) {
+    if (!g || !h_out || !c_out || (Ch % 4) != 0 || (g_ld % 4) != 0 || (h_ld % 4) != 0 || (c_ld % 4) != 0 ||
+        (g_bs % 4) != 0 || (h_bs % 4) != 0 || (c_bs % 4) != 0 || g_ld < 4 * Ch)
+        return hipErrorInvalidValue;
+    if (c_prev && ((cp_ld % 4) != 0 || (cp_bs % 4) != 0)) return hipErrorInvalidValue;
+    const long total = (long)B * HW * (Ch / 4);
+    hipLaunchKernelGGL(lstm_cell_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g, g_ld, g_bs, c_prev,
+                       cp_ld, cp_bs, h_out, h_ld, h_bs, c_out, c_ld, c_bs, B, HW, Ch);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// correlation pyramid: F.avg_pool2d(corr, 2, stride=2) over the (h2,w2) plane of every
+// (b, i) row -- DCEIFlow/core/corr/raft_corr.py:28-30.
+// ---------------------------------------------------------------------------
+__global__ void corr_pool_kernel(const float* __restrict__ src, float* __restrict__ dst, long rows, int Hs, int Ws) {
+    const int Hd = Hs / 2, Wd = Ws / 2;
+    const long total = rows * Hd * Wd;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int x = (int)(gid % Wd);
+    const int y = (int)((gid / Wd) % Hd);
+    const long r = gid / ((long)Wd * Hd);
+    const float* s = src + r * Hs * Ws + (long)(2 * y) * Ws + 2 * x;
+    const float sum = ((s[0] + s[1]) + s[Ws]) + s[Ws + 1];
+    dst[gid] = sum / 4.f;
+}
+
+hipError_t launch_corr_pool(const float* src, float* dst, long rows, int Hs, int Ws, hipStream_t s) {
+    if (!src || !dst || rows <= 0 || Hs < 2 || Ws < 2) return hipErrorInvalidValue;
+    const long total = rows * (Hs / 2) * (Ws / 2);
+    hipLaunchKernelGGL(corr_pool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst, rows, Hs, Ws);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// correlation lookup (a10): raft_corr.py:32-54 + sample_utils.py:38-52.
+// channel lvl*(2r+1)^2 + a*(2r+1) + bb  =  zero-padded bilinear sample of level lvl at
+// (x/2^lvl + a - r, y/2^lvl + bb - r).  One wave per query pixel, lanes over channels.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void corr_lookup_kernel(const LookupParams p) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long N = (long)p.h8 * p.w8;
+    const long qid = (long)blockIdx.x * 4 + wave;
+    if (qid >= (long)p.B * N) return;
+    const int b = (int)(qid / N);
+    const int i = (int)(qid % N);
+    const int qy = i / p.w8, qx = i % p.w8;
+    const float cx = p.coords1[((long)b * 2 + 0) * N + i];
+    const float cy = p.coords1[((long)b * 2 + 1) * N + i];
+    const int d = 2 * p.radius + 1;
+    const int per = d * d;
+    const int nch = p.nlevels * per;
+    float* o = p.out + ((long)b * N + i) * p.out_ld;
+    for (int ch = lane; ch < p.out_ld; ch += 64) {
+        float val = 0.f;
+        if (ch < nch) {
+            const int lvl = ch / per;
+            const int rem = ch - lvl * per;
+            const int a = rem / d, bb = rem - a * d;
+            const int Hl = lvl == 0 ? p.lh[0] : (lvl == 1 ? p.lh[1] : (lvl == 2 ? p.lh[2] : p.lh[3]));
+            const int Wl = lvl == 0 ? p.lw[0] : (lvl == 1 ? p.lw[1] : (lvl == 2 ? p.lw[2] : p.lw[3]));
+            const float* base = lvl == 0 ? p.lvl[0] : (lvl == 1 ? p.lvl[1] : (lvl == 2 ? p.lvl[2] : p.lvl[3]));
+            const float* plane = base + ((long)b * N + i) * Hl * Wl;
+            const float div = (float)(1 << lvl);
+            const float x = cx / div + (float)(a - p.radius);
+            const float y = cy / div + (float)(bb - p.radius);
+            // bilinear_sampler: g = 2*x/(W-1) - 1 ; grid_sample(align_corners=True): (g+1)*((W-1)/2)
+            const float gx = 2.f * x / (float)(Wl - 1) - 1.f;
+            const float gy = 2.f * y / (float)(Hl - 1) - 1.f;
+            const float ix = (gx + 1.f) * ((float)(Wl - 1) / 2.f);
+            const float iy = (gy + 1.f) * ((float)(Hl - 1) / 2.f);
+            const float fx = floorf(ix), fy = floorf(iy);
+            const float tx = ix - fx, ty = iy - fy;
+            // float compare before the int cast keeps huge / NaN coordinates out of range
+            const bool inx0 = fx >= 0.f && fx <= (float)(Wl - 1);
+            const bool inx1 = fx + 1.f >= 0.f && fx + 1.f <= (float)(Wl - 1);
+            const bool iny0 = fy >= 0.f && fy <= (float)(Hl - 1);
+            const bool iny1 = fy + 1.f >= 0.f && fy + 1.f <= (float)(Hl - 1);
+            const int x0 = inx0 ? (int)fx : 0, x1 = inx1 ? (int)fx + 1 : 0;
+            const int y0 = iny0 ? (int)fy : 0, y1 = iny1 ? (int)fy + 1 : 0;
+            const float v00 = (inx0 && iny0) ? plane[(long)y0 * Wl + x0] : 0.f;
+            const float v01 = (inx1 && iny0) ? plane[(long)y0 * Wl + x1] : 0.f;
+            const float v10 = (inx0 && iny1) ? plane[(long)y1 * Wl + x0] : 0.f;
+            const float v11 = (inx1 && iny1) ? plane[(long)y1 * Wl + x1] : 0.f;
+            val = v00 * ((1.f - tx) * (1.f - ty)) + v01 * (tx * (1.f - ty)) + v10 * ((1.f - tx) * ty) + v11 * (tx * ty);
+        }
+        o[ch] = val;
+    }
+    if (p.motion && lane < 2) {
+        // flow = coords1 - coords0 ; coords0 = pixel grid (sample_utils.py:55-58)
+        const float f = lane == 0 ? (cx - (float)qx) : (cy - (float)qy);
+        p.motion[((long)b * N + i) * p.mo_ld + p.mo_off + lane] = f;
+    }
+}
+
+hipError_t launch_corr_lookup(const LookupParams& p, hipStream_t s) {
+    if (p.nlevels < 1 || p.nlevels > 4 || p.radius < 0 || !p.out || !p.coords1) return hipErrorInvalidValue;
+    const int d = 2 * p.radius + 1;
+    if (p.out_ld < p.nlevels * d * d) return hipErrorInvalidValue;
+    for (int l = 0; l < p.nlevels; ++l)
+        if (!p.lvl[l] || p.lh[l] < 2 || p.lw[l] < 2) return hipErrorInvalidValue;
+    const long nq = (long)p.B * p.h8 * p.w8;
+    hipLaunchKernelGGL(corr_lookup_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// coords1 = coords_grid (+ flow_init)   DCEIFlow.py:96-104,198-201
+// ---------------------------------------------------------------------------
+__global__ void coords_init_kernel(float* coords1, const float* flow_init, int B, int h8, int w8) {
+    const long N = (long)h8 * w8;
+    const long total = (long)B * 2 * N;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int i = (int)(gid % N);
+    const int ch = (int)((gid / N) % 2);
+    float v = ch == 0 ? (float)(i % w8) : (float)(i / w8);
+    if (flow_init) v = v + flow_init[gid];
+    coords1[gid] = v;
+}
+
+hipError_t launch_coords_init(float* coords1, const float* flow_init, int B, int h8, int w8, hipStream_t s) {
+    if (!coords1 || B <= 0 || h8 <= 0 || w8 <= 0) return hipErrorInvalidValue;
+    const long total = (long)B * 2 * h8 * w8;
+    hipLaunchKernelGGL(coords_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, coords1, flow_init, B,
+                       h8, w8);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// upflow8 (sample_utils.py:66-68): ds * interpolate(flow, x ds, bilinear, align_corners=True),
+// then ImagePadder.unpad (image_process.py:103-107).  Also raises the ".any()" flag.
+// ---------------------------------------------------------------------------
+__global__ void upflow_kernel(const float* __restrict__ coords1, int B, int h8, int w8, int ds, float* flow_up,
+                              float* flow_final, int H, int W, int padH, int padW, int* flag) {
+    const int Hp = h8 * ds, Wp = w8 * ds;
+    const long total = (long)B * 2 * Hp * Wp;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    bool nz = false;
+    if (gid < total) {
+        const int x = (int)(gid % Wp);
+        const int y = (int)((gid / Wp) % Hp);
+        const int ch = (int)((gid / ((long)Wp * Hp)) % 2);
+        const int b = (int)(gid / ((long)Wp * Hp * 2));
+        int y0, y1, x0, x1;
+        float ly0, ly1, lx0, lx1;
+        ac_true_src(y, h8, Hp, y0, y1, ly0, ly1);
+        ac_true_src(x, w8, Wp, x0, x1, lx0, lx1);
+        const float* c = coords1 + ((long)b * 2 + ch) * h8 * w8;
+        // flow = coords1 - coords0 at the four taps
+        const float g00 = ch == 0 ? (float)x0 : (float)y0;
+        const float g01 = ch == 0 ? (float)x1 : (float)y0;
+        const float g10 = ch == 0 ? (float)x0 : (float)y1;
+        const float g11 = ch == 0 ? (float)x1 : (float)y1;
+        const float v00 = c[(long)y0 * w8 + x0] - g00, v01 = c[(long)y0 * w8 + x1] - g01;
+        const float v10 = c[(long)y1 * w8 + x0] - g10, v11 = c[(long)y1 * w8 + x1] - g11;
+        const float v = (float)ds * (ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11));
+        if (flow_up) flow_up[gid] = v;
+        if (flow_final && y >= padH && x >= padW) {
+            flow_final[(((long)b * 2 + ch) * H + (y - padH)) * W + (x - padW)] = v;
+            nz = v != 0.0f;
+        }
+    }
+    if (flag && __any(nz)) {
+        if ((threadIdx.x & 63) == 0) *flag = 1;
+    }
+}
+
+hipError_t launch_upflow(const float* coords1, int B, int h8, int w8, int ds, float* flow_up, float* flow_final, int H,
+                         int W, int padH, int padW, int* flag, hipStream_t s) {
+    if (!coords1 || B <= 0 || h8 <= 0 || w8 <= 0 || ds <= 0) return hipErrorInvalidValue;
+    if (flow_final && (H + padH != h8 * ds || W + padW != w8 * ds)) return hipErrorInvalidValue;
+    const long total = (long)B * 2 * h8 * ds * w8 * ds;
+    hipLaunchKernelGGL(upflow_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, coords1, B, h8, w8, ds,
+                       flow_up, flow_final, H, W, padH, padW, flag);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// boundary shuffles (recurrent states arrive / leave as whatever the caller holds)
+// ---------------------------------------------------------------------------
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int dst_ld, int B, int C,
+                                    int HW) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, p = p0 + tx;
+        tile[k][tx] = (c < C && p < HW) ? src[((long)b * C + c) * HW + p] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int p = p0 + k, c = c0 + tx;
+        if (p < HW && c < C) dst[((long)b * HW + p) * dst_ld + c] = tile[tx][k];
+    }
+}
+
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, int src_ld, float* __restrict__ dst, int B, int C,
+                                    int HW) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8) {
+        const int p = p0 + k, c = c0 + tx;
+        tile[k][tx] = (c < C && p < HW) ? src[((long)b * HW + p) * src_ld + c] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, p = p0 + tx;
+        if (p < HW && c < C) dst[((long)b * C + c) * HW + p] = tile[tx][k];
+    }
+}
+
+hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int dst_ld, int B, int C, int HW, hipStream_t s) {
+    if (!src || !dst || dst_ld < C) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((HW + 31) / 32, (C + 31) / 32, B), dim3(256), 0, s, src, dst, dst_ld, B, C,
+                       HW);
+    return hipGetLastError();
+}
+hipError_t launch_nhwc_to_nchw(const float* src, int src_ld, float* dst, int B, int C, int HW, hipStream_t s) {
+    if (!src || !dst || src_ld < C) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((HW + 31) / 32, (C + 31) / 32, B), dim3(256), 0, s, src, src_ld, dst, B, C,
+                       HW);
+    return hipGetLastError();
+}
+
+}  // namespace cf

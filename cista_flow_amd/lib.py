@@ -1,0 +1,150 @@
+"""ctypes binding of libcistaflow.so (include/cistaflow.h).
+
+The product path has no CPU fallback: if the HIP library is missing or cannot be loaded this
+module raises, and every op that needs it raises with it.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcistaflow.so")
+
+CF_MODE_CISTA, CF_MODE_EIFLOW, CF_MODE_ERAFT, CF_MODE_IDNET = 0, 1, 2, 3
+CF_WARP_FORWARD, CF_WARP_BACKWARD = 0, 1
+
+# every symbol include/cistaflow.h declares (tests check the .so exports exactly these)
+SYMBOLS = [
+    "cf_create", "cf_destroy", "cf_last_error", "cf_workspace_bytes", "cf_load_weights",
+    "cf_finalize_weights", "cf_warp", "cf_cista_forward", "cf_flow_forward", "cf_step",
+    "cf_op_conv2d", "cf_op_instance_norm_relu", "cf_op_corr_lookup", "cf_op_nchw_to_nhwc",
+    "cf_op_nhwc_to_nchw",
+]
+
+
+class cf_config(C.Structure):
+    _fields_ = [
+        ("mode", C.c_int), ("batch", C.c_int), ("height", C.c_int), ("width", C.c_int),
+        ("num_bins", C.c_int), ("base_channels", C.c_int), ("depth", C.c_int), ("iters", C.c_int),
+        ("warp_mode", C.c_int), ("device", C.c_int),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load libcistaflow.so (built by __graft_entry__.build()); raises if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libcistaflow.so not found at %s -- build it first (python -c 'import __graft_entry__ as g; g.build()'). "
+            "There is no CPU fallback for the CISTA-Flow hot path." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    fp, vp, i = C.c_void_p, C.c_void_p, C.c_int
+    lib.cf_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(cf_config)]
+    lib.cf_create.restype = i
+    lib.cf_destroy.argtypes = [vp]
+    lib.cf_destroy.restype = None
+    lib.cf_last_error.argtypes = [vp]
+    lib.cf_last_error.restype = C.c_char_p
+    lib.cf_workspace_bytes.argtypes = [vp]
+    lib.cf_workspace_bytes.restype = C.c_size_t
+    lib.cf_load_weights.argtypes = [vp, C.c_char_p, vp, C.POINTER(C.c_int64), i]
+    lib.cf_load_weights.restype = i
+    lib.cf_finalize_weights.argtypes = [vp, vp]
+    lib.cf_finalize_weights.restype = i
+    lib.cf_warp.argtypes = [vp, fp, fp, fp, i, i, i, i, i, i, i, vp]
+    lib.cf_warp.restype = i
+    lib.cf_cista_forward.argtypes = [vp] + [fp] * 11 + [vp]
+    lib.cf_cista_forward.restype = i
+    lib.cf_flow_forward.argtypes = [vp] + [fp] * 6 + [vp]
+    lib.cf_flow_forward.restype = i
+    lib.cf_step.argtypes = [vp] + [fp] * 18 + [vp]
+    lib.cf_step.restype = i
+    lib.cf_op_conv2d.argtypes = [fp, i, i, i, i, fp, fp, i, i, i, i, i, i, i, i, i, i, fp, vp]
+    lib.cf_op_conv2d.restype = i
+    lib.cf_op_instance_norm_relu.argtypes = [fp, fp, i, i, i, i, C.c_float, vp]
+    lib.cf_op_instance_norm_relu.restype = i
+    lib.cf_op_corr_lookup.argtypes = [fp, fp, fp, fp, i, i, i, i, vp]
+    lib.cf_op_corr_lookup.restype = i
+    lib.cf_op_nchw_to_nhwc.argtypes = [fp, fp, i, i, i, i, vp]
+    lib.cf_op_nchw_to_nhwc.restype = i
+    lib.cf_op_nhwc_to_nchw.argtypes = [fp, fp, i, i, i, i, vp]
+    lib.cf_op_nhwc_to_nchw.restype = i
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """Raw device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def current_stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check_f32_cuda(t, name, shape=None):
+    import torch
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s must live on the GPU (cista_flow_amd has no CPU path)" % name)
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32, got %s" % (name, t.dtype))
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError("%s: expected shape %s, got %s" % (name, tuple(shape), tuple(t.shape)))
+
+
+class Handle:
+    """Owns one cf_handle (workspace arena + packed weights) for a fixed (mode, B, H, W)."""
+
+    def __init__(self, mode, batch, height, width, num_bins=5, base_channels=64, depth=5, iters=6,
+                 warp_mode=CF_WARP_FORWARD, device=0):
+        self.lib = load()
+        self.cfg = cf_config(mode, batch, height, width, num_bins, base_channels, depth, iters, warp_mode, device)
+        h = C.c_void_p()
+        rc = self.lib.cf_create(C.byref(h), C.byref(self.cfg))
+        if rc != 0:
+            raise RuntimeError("cf_create failed (%d): %s" % (rc, self.lib.cf_last_error(None).decode()))
+        self.h = h
+        self._keep = []
+
+    def check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, self.lib.cf_last_error(self.h).decode()))
+
+    def load_state_dict(self, sd):
+        """Announce every fp32 tensor of a reference-layout state_dict and pack on the current stream."""
+        import torch
+        keep = []
+        for k, v in sd.items():
+            if not isinstance(v, torch.Tensor) or v.dtype != torch.float32:
+                continue   # num_batches_tracked (int64) is not used in eval
+            t = v.detach().contiguous()
+            check_f32_cuda(t, k)
+            keep.append(t)
+            shp = (C.c_int64 * max(1, t.dim()))(*t.shape)
+            self.check(self.lib.cf_load_weights(self.h, k.encode(), ptr(t), shp, t.dim()), "cf_load_weights(%s)" % k)
+        self.check(self.lib.cf_finalize_weights(self.h, current_stream_ptr()), "cf_finalize_weights")
+        del keep
+
+    @property
+    def workspace_bytes(self):
+        return int(self.lib.cf_workspace_bytes(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.cf_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,118 @@
+/* cistaflow.h -- C ABI of libcistaflow.so, the MI355X (gfx950) hot path of CISTA-Flow.
+ *
+ * The reference (lsying009/CISTA-Flow) is pure Python/PyTorch and has no FFI of its own; the
+ * boundary this library replaces is the Python module API of
+ *     e2v/e2v_model.py:10-98    CistaLSTCNet.forward              -> cf_cista_forward
+ *     DCEIFlow/DCEIFlow.py:143  DCEIFlow.forward                  -> cf_flow_forward
+ *     utils/flow_utils.py:193   FrameWarp.warp_frame              -> cf_warp
+ *     e2v/e2v_model.py:144-196  DCEIFlowCistaNet.forward (a5)     -> cf_step
+ * The Python shells in cista_flow_amd/ bind these entry points with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 data owned by the caller (PyTorch); the library
+ *     owns only its per-handle workspace arena and the packed weight copies;
+ *   - "NCHW" tensors are contiguous [B][C][H][W]; "NHWC" tensors are contiguous [B][H][W][C]
+ *     (torch channels_last memory of a logical [B,C,H,W] tensor);
+ *   - calls are asynchronous on `stream` (a hipStream_t), never synchronise the device, are not
+ *     re-entrant per handle, and introduce no host round trip (the reference's per-frame
+ *     `flow_final.any()` sync, e2v_model.py:184, becomes a device-side flag);
+ *   - return value: 0 = ok, negative = error (message via cf_last_error); no exceptions cross.
+ */
+#ifndef CISTAFLOW_H
+#define CISTAFLOW_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cf_handle cf_handle;
+
+enum { CF_MODE_CISTA = 0, CF_MODE_EIFLOW = 1, CF_MODE_ERAFT = 2, CF_MODE_IDNET = 3 };
+enum { CF_WARP_FORWARD = 0, CF_WARP_BACKWARD = 1 };
+
+enum {
+    CF_OK = 0,
+    CF_ERR_ARG = -1,      /* bad argument / shape */
+    CF_ERR_HIP = -2,      /* HIP runtime error */
+    CF_ERR_STATE = -3,    /* call order (e.g. forward before weights were finalised) */
+    CF_ERR_WEIGHT = -4,   /* missing / mis-shaped weight */
+    CF_ERR_UNSUPPORTED = -5
+};
+
+typedef struct cf_config {
+    int mode;           /* CF_MODE_* */
+    int batch;          /* B: independent sequences held by this handle */
+    int height, width;  /* image_dim (utils/configs.py:6); must be even */
+    int num_bins;       /* 5  (configs.py:18) */
+    int base_channels;  /* 64 (configs.py:22) */
+    int depth;          /* 5 ISTA iterations (configs.py:20) */
+    int iters;          /* flow-net refinement iterations: 6 eiflow (DCEIFlow.py:143), 12 eraft */
+    int warp_mode;      /* CF_WARP_* (configs.py:94) */
+    int device;         /* HIP device ordinal */
+} cf_config;
+
+/* lifetime ---------------------------------------------------------------------------------- */
+int cf_create(cf_handle** out, const cf_config* cfg);
+void cf_destroy(cf_handle* h);
+const char* cf_last_error(const cf_handle* h);   /* h may be NULL: last create() error */
+size_t cf_workspace_bytes(const cf_handle* h);
+
+/* weights: announce every state_dict entry (name = reference state_dict key, fp32, contiguous,
+ * PyTorch layout e.g. OIHW), then cf_finalize_weights packs them on `stream` (BatchNorm folded,
+ * K-contiguous [cout][tap][cin] matrices).  The announced pointers are only read during
+ * cf_finalize_weights.  Replaces nn.Module.load_state_dict + .to(device) for the hot path. */
+int cf_load_weights(cf_handle* h, const char* name, const void* dev_ptr, const int64_t* shape, int ndim);
+int cf_finalize_weights(cf_handle* h, void* stream);
+
+/* a4  FrameWarp.warp_frame (utils/flow_utils.py:212-221).  img/out NHWC [B][H][W][C] (C == 1:
+ * identical to NCHW), flow NCHW [B][2][Hf][Wf]; (Hf,Wf) != (H,W) resamples the flow first with
+ * interpolate(bilinear, align_corners=True) without rescaling values (e2v_model.py:190). */
+int cf_warp(cf_handle* h, const float* img, const float* flow, float* out, int B, int C, int H, int W,
+            int Hf, int Wf, int mode, void* stream);
+
+/* a3  CistaLSTCNet.forward (e2v/e2v_model.py:49-98).
+ *   ev NCHW [B][bins][H][W], img NCHW [B][1][H][W];
+ *   states NHWC at (H/2,W/2): c,z 2*base channels; h,cc base channels; *_prev may be NULL (zeros). */
+int cf_cista_forward(cf_handle* h, const float* ev, const float* img, const float* c_prev, const float* z_prev,
+                     const float* h_prev, const float* cc_prev, float* I_out, float* c_out, float* z_out,
+                     float* h_out, float* cc_out, void* stream);
+
+/* a13/a14  flow network forward.
+ *   eiflow: in0 = event_voxel [B][bins][H][W], in1 = image1 [B][1][H][W]   (DCEIFlow.py:143)
+ *   flow_init NCHW [B][2][Hp/8][Wp/8] or NULL; flow_final NCHW [B][2][H][W];
+ *   flow_low (nullable) NCHW [B][2][Hp/8][Wp/8] = coords1 - coords0 ("flow_init" of the dict);
+ *   flow_preds (nullable) NCHW [iters][B][2][Hp][Wp] = every iteration's padded up-sampled flow. */
+int cf_flow_forward(cf_handle* h, const float* in0, const float* in1, const float* flow_init, float* flow_final,
+                    float* flow_low, float* flow_preds, void* stream);
+
+/* a5  one reconstructed frame: flow net -> any() -> warp I, warp Z -> CISTA-LSTC
+ * (e2v/e2v_model.py:144-196).  gt_flow (nullable) overrides the estimated flow for the warp
+ * (e2v_model.py:181-182).  z_warped_out (nullable unless z_prev != NULL) receives the warped
+ * sparse code the reference stores back into the caller's states[1] (e2v_model.py:191). */
+int cf_step(cf_handle* h, const float* in0, const float* in1, const float* rec_img0, const float* flow_init,
+            const float* gt_flow, const float* c_prev, const float* z_prev, const float* h_prev,
+            const float* cc_prev, float* I_out, float* flow_final, float* flow_low, float* flow_preds,
+            float* z_warped_out, float* c_out, float* z_out, float* h_out, float* cc_out, void* stream);
+
+/* single-operator entry points (used by the parity tests; same kernels as the fused paths) ------ */
+/* conv2d on NHWC input (a_mode 0), fused x2-upsample input (a_mode 1) or planar NCHW small-Cin input
+ * (a_mode 2); weight OIHW; out NHWC [B][Ho][Wo][Cout].  epi: 0 none 1 relu 2 sigmoid 3 tanh. */
+int cf_op_conv2d(const float* in, int B, int Cin, int H, int W, const float* weight, const float* bias, int Cout,
+                 int KH, int KW, int stride, int padT, int padL, int pad_mode, int a_mode, int epi, int tile,
+                 float* out, void* stream);
+int cf_op_instance_norm_relu(const float* x_nhwc, float* out_nhwc, int B, int C, int H, int W, float eps,
+                             void* stream);
+/* all-pairs correlation + pyramid + lookup (a9/a10): fmaps NHWC [B][h][w][D], coords NCHW [B][2][h][w];
+ * out NHWC [B][h][w][4*81] */
+int cf_op_corr_lookup(const float* fmap1, const float* fmap2, const float* coords, float* out, int B, int D, int h,
+                      int w, void* stream);
+int cf_op_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, void* stream);
+int cf_op_nhwc_to_nchw(const float* src, float* dst, int B, int C, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CISTAFLOW_H */

@@ -1,0 +1,373 @@
+"""CPU oracle of the CISTA-Flow inference hot path (cista-eiflow) -- TEST INFRASTRUCTURE ONLY.
+
+A functional restatement, written from the reference's semantics, of
+    CistaLSTCNet.forward            /root/reference/e2v/e2v_model.py:49-98
+    ConvLSTC / ConvLSTM / ConvLayer /root/reference/e2v/base_layers.py:38-71, 75-132, 137-212
+    forwardWarp / backWarp          /root/reference/utils/flow_utils.py:83-120, 153-190
+    ImagePadder                     /root/reference/utils/image_process.py:60-107
+    DCEIFlow.forward                /root/reference/DCEIFlow/DCEIFlow.py:32-44, 143-227, 295-299
+    BasicEncoder / ResidualBlock    /root/reference/DCEIFlow/core/backbone/raft_encoder.py:6-59, 125-203
+    CorrBlock                       /root/reference/DCEIFlow/core/corr/raft_corr.py:15-65
+    bilinear_sampler, upflow8       /root/reference/DCEIFlow/utils/sample_utils.py:38-68
+    BasicUpdateBlockNoMask          /root/reference/DCEIFlow/core/decoder/with_event_updater.py:6-14, 35-67, 90-112, 156-171
+    DCEIFlowCistaNet.forward (a5)   /root/reference/e2v/e2v_model.py:144-196
+
+Weights come in as a plain dict keyed by the reference's state_dict names.  The only "heavy"
+primitive used is F.conv2d; every resampling op (grid_sample, interpolate, avg_pool, instance /
+batch norm) is written out as explicit index arithmetic so the semantics the HIP kernels must
+reproduce are stated here and nowhere else.
+
+Pinning: tests/test_oracle_golden.py checks this file against tests/golden/*.npz, which
+tools/gen_golden.py produced by importing and running the reference itself in the build
+container (the reference has no tests / golden vectors of its own -- SURVEY.md section 4).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+# ----------------------------------------------------------------------------------------------
+# elementary ops
+# ----------------------------------------------------------------------------------------------
+
+
+def conv2d(x, w, b, stride=1, pad=(0, 0), mode="zeros"):
+    """nn.Conv2d with padding_mode 'zeros' | 'reflect' (pad = (padH, padW))."""
+    ph, pw = pad
+    if mode == "reflect":
+        if ph or pw:
+            x = reflect_pad(x, ph, pw)
+        return F.conv2d(x, w, b, stride=stride)
+    return F.conv2d(x, w, b, stride=stride, padding=(ph, pw))
+
+
+def reflect_pad(x, ph, pw):
+    """mirror without repeating the edge sample: index -1 -> 1, H -> H-2."""
+    H, W = x.shape[-2:]
+    iy = torch.arange(-ph, H + ph).abs()
+    iy = torch.where(iy >= H, 2 * (H - 1) - iy, iy)
+    ix = torch.arange(-pw, W + pw).abs()
+    ix = torch.where(ix >= W, 2 * (W - 1) - ix, ix)
+    return x[..., iy, :][..., ix]
+
+
+def softshrink(x, lambd):
+    """base_layers.py:11-12"""
+    return torch.relu(x - lambd) - torch.relu(-x - lambd)
+
+
+def _lin_src(out_size, in_size, align_corners):
+    """source indices / weights of 1-D linear interpolation as ATen computes them."""
+    d = torch.arange(out_size, dtype=torch.float32)
+    if align_corners:
+        scale = (in_size - 1) / (out_size - 1) if out_size > 1 else 0.0
+        src = torch.tensor(scale, dtype=torch.float32) * d
+    else:
+        scale = in_size / out_size
+        src = torch.tensor(scale, dtype=torch.float32) * (d + 0.5) - 0.5
+        src = src.clamp(min=0)
+    i0 = src.floor().long().clamp(max=in_size - 1)
+    i1 = torch.where(i0 < in_size - 1, i0 + 1, i0)
+    l1 = src - i0.float()
+    l0 = 1.0 - l1
+    return i0, i1, l0, l1
+
+
+def interp_bilinear(x, out_h, out_w, align_corners):
+    """F.interpolate(x, size=(out_h,out_w), mode='bilinear', align_corners=...)."""
+    H, W = x.shape[-2:]
+    y0, y1, ly0, ly1 = _lin_src(out_h, H, align_corners)
+    x0, x1, lx0, lx1 = _lin_src(out_w, W, align_corners)
+    top = x[..., y0, :]
+    bot = x[..., y1, :]
+    t = lx0 * top[..., x0] + lx1 * top[..., x1]
+    b = lx0 * bot[..., x0] + lx1 * bot[..., x1]
+    return ly0[:, None] * t + ly1[:, None] * b
+
+
+def _reflect_coord(x, size):
+    """ATen grid_sampler reflection about [0, size-1] (align_corners=True), then clip."""
+    if size <= 1:
+        return torch.zeros_like(x)
+    twice_span = float(2 * (size - 1))
+    a = x.abs()
+    flips = torch.trunc(a / twice_span)
+    extra = a - flips * twice_span
+    r = torch.minimum(extra, twice_span - extra)
+    return r.clamp(0, size - 1)
+
+
+def warp(img, flow, mode="forward"):
+    """a4: grid_sample(img, g, bilinear, align_corners=True, padding_mode='reflection') with
+    g = 2*((x -/+ u)/W - 0.5): the sampled pixel is (x -/+ u)*(W-1)/W -- zero flow is NOT identity."""
+    B, C, H, W = img.shape
+    gy, gx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    u, v = flow[:, 0], flow[:, 1]
+    if mode == "forward":
+        xs, ys = gx[None].float() - u, gy[None].float() - v
+    else:
+        xs, ys = gx[None].float() + u, gy[None].float() + v
+    xs = 2 * (xs / W - 0.5)
+    ys = 2 * (ys / H - 0.5)
+    ix = (xs + 1) * ((W - 1) / 2)
+    iy = (ys + 1) * ((H - 1) / 2)
+    ix = _reflect_coord(ix, W)
+    iy = _reflect_coord(iy, H)
+    x0, y0 = ix.floor(), iy.floor()
+    tx, ty = ix - x0, iy - y0
+    x0, y0 = x0.long(), y0.long()
+    x1, y1 = x0 + 1, y0 + 1
+    flat = img.reshape(B, C, H * W)
+
+    def tap(yy, xx):
+        ok = ((xx >= 0) & (xx < W) & (yy >= 0) & (yy < H)).float()
+        idx = (yy.clamp(0, H - 1) * W + xx.clamp(0, W - 1)).reshape(B, 1, H * W).expand(B, C, H * W)
+        return flat.gather(2, idx).reshape(B, C, H, W) * ok[:, None]
+
+    w00 = ((1 - ty) * (1 - tx))[:, None]
+    w01 = ((1 - ty) * tx)[:, None]
+    w10 = (ty * (1 - tx))[:, None]
+    w11 = (ty * tx)[:, None]
+    return tap(y0, x0) * w00 + tap(y0, x1) * w01 + tap(y1, x0) * w10 + tap(y1, x1) * w11
+
+
+# ----------------------------------------------------------------------------------------------
+# CISTA-LSTC  (a3)
+# ----------------------------------------------------------------------------------------------
+
+
+def _cl(sd, pre, x, stride=1, pad=1):
+    return conv2d(x, sd[pre + ".weight"], sd[pre + ".bias"], stride, (pad, pad), "reflect")
+
+
+def cista_forward(sd, events, prev_image, prev_states, depth=5, prefix="cista_net."):
+    """CistaLSTCNet.forward.  Returns (rec_I, [c, z, (h, cc)])."""
+    p = prefix
+    if prev_states is None:
+        prev_states = [None, None, None]
+    x_E = _cl(sd, p + "We.conv2d", events)
+    x_I = _cl(sd, p + "Wi.conv2d", prev_image)
+    x1 = _cl(sd, p + "W0.conv2d", torch.cat((x_E, x_I), 1), stride=2)
+    # ConvLSTC
+    z_prev, c_prev = prev_states[1], prev_states[0]
+    B, _, h, w = x1.shape
+    zc = sd[p + "P0.P0.weight"].shape[0]
+    if z_prev is None:
+        z_prev = torch.zeros(B, zc, h, w)
+    gates = _cl(sd, p + "P0.gates", torch.cat((x1, z_prev), 1))
+    in_gate, forget_gate = torch.sigmoid(gates[:, :zc]), torch.sigmoid(gates[:, zc:])
+    z0 = _cl(sd, p + "P0.P0", x1)
+    out_gate = torch.sigmoid(_cl(sd, p + "P0.out_gates", torch.cat((z0, z_prev), 1)))
+    if c_prev is None:
+        c_prev = torch.zeros_like(z0)
+    c = forget_gate * c_prev + in_gate * z0
+    z = out_gate * torch.tanh(c)
+    # unrolled ISTA: lista_blocks.0..4 alias one IstaBlock
+    lam = sd[p + "lista_blocks.0.Lambda"]
+    tmp = z
+    for i in range(depth):
+        k = p + "lista_blocks.%d." % i
+        tmp = _cl(sd, k + "D.conv2d", tmp)
+        x = _cl(sd, k + "P.conv2d", x1 - tmp) + z
+        z = softshrink(x, sd[k + "Lambda"])
+        tmp = z
+    # Dg: conv+relu then ConvLSTM (chunk order in, remember, out, cell)
+    x = torch.relu(_cl(sd, p + "Dg.conv.conv2d", z))
+    hc = x.shape[1]
+    if prev_states[2] is None:
+        h_prev, cc_prev = torch.zeros_like(x), torch.zeros_like(x)
+    else:
+        h_prev, cc_prev = prev_states[2]
+    g = _cl(sd, p + "Dg.recurrent_block.Gates", torch.cat((x, h_prev), 1))
+    ig, rg, og, cg = g[:, :hc], g[:, hc:2 * hc], g[:, 2 * hc:3 * hc], g[:, 3 * hc:]
+    cc = torch.sigmoid(rg) * cc_prev + torch.sigmoid(ig) * torch.tanh(cg)
+    hh = torch.sigmoid(og) * torch.tanh(cc)
+    # upsample x2 (align_corners=False) + ReflectionPad2d(1) + conv(pad 0) + relu ; final conv + sigmoid
+    up = interp_bilinear(hh, 2 * hh.shape[2], 2 * hh.shape[3], align_corners=False)
+    up = torch.relu(F.conv2d(reflect_pad(up, 1, 1), sd[p + "upsamp_conv.conv2d.weight"], sd[p + "upsamp_conv.conv2d.bias"]))
+    rec = torch.sigmoid(_cl(sd, p + "final_conv.conv2d", up))
+    return rec, [c, z, (hh, cc)]
+
+
+# ----------------------------------------------------------------------------------------------
+# DCEIFlow  (a6 - a13)
+# ----------------------------------------------------------------------------------------------
+
+
+def image_pad(x, H, W, min_size=32):
+    """ImagePadder.pad: zero pad TOP and LEFT up to a multiple of min_size."""
+    ph = (min_size - H % min_size) % min_size
+    pw = (min_size - W % min_size) % min_size
+    return F.pad(x, (pw, 0, ph, 0)), ph, pw
+
+
+def instance_norm(x, eps=1e-5):
+    m = x.mean(dim=(2, 3), keepdim=True)
+    v = ((x - m) ** 2).mean(dim=(2, 3), keepdim=True)
+    return (x - m) / torch.sqrt(v + eps)
+
+
+def batch_norm_eval(x, sd, pre, eps=1e-5):
+    w, b = sd[pre + ".weight"], sd[pre + ".bias"]
+    m, v = sd[pre + ".running_mean"], sd[pre + ".running_var"]
+    return (x - m[None, :, None, None]) / torch.sqrt(v[None, :, None, None] + eps) * w[None, :, None, None] + b[None, :, None, None]
+
+
+def encoder(sd, pre, x, norm):
+    """BasicEncoder (ds=8).  norm: 'instance' | 'batch'."""
+
+    def nrm(t, name):
+        return instance_norm(t) if norm == "instance" else batch_norm_eval(t, sd, name)
+
+    x = conv2d(x, sd[pre + ".conv1.weight"], sd[pre + ".conv1.bias"], 2, (3, 3))
+    x = torch.relu(nrm(x, pre + ".norm1"))
+    for L, stride0 in ((1, 1), (2, 2), (3, 2)):
+        for blk in range(2):
+            k = "%s.layer%d.%d" % (pre, L, blk)
+            stride = stride0 if blk == 0 else 1
+            y = conv2d(x, sd[k + ".conv1.weight"], sd[k + ".conv1.bias"], stride, (1, 1))
+            y = torch.relu(nrm(y, k + ".norm1"))
+            y = conv2d(y, sd[k + ".conv2.weight"], sd[k + ".conv2.bias"], 1, (1, 1))
+            y = torch.relu(nrm(y, k + ".norm2"))
+            if stride != 1:
+                x = conv2d(x, sd[k + ".downsample.0.weight"], sd[k + ".downsample.0.bias"], stride, (0, 0))
+                x = nrm(x, k + ".downsample.1")
+            x = torch.relu(x + y)
+    return conv2d(x, sd[pre + ".conv2.weight"], sd[pre + ".conv2.bias"], 1, (0, 0))
+
+
+def corr_pyramid(fmap1, fmap2, levels=4):
+    """all-pairs correlation / sqrt(D) and its 2x2 average pyramid: list of [B*N,1,h,w]."""
+    B, D, h, w = fmap1.shape
+    f1 = fmap1.reshape(B, D, h * w)
+    f2 = fmap2.reshape(B, D, h * w)
+    corr = torch.matmul(f1.transpose(1, 2), f2) * (1.0 / math.sqrt(D))
+    corr = corr.reshape(B * h * w, 1, h, w)
+    pyr = [corr]
+    for _ in range(levels - 1):
+        hh, ww = corr.shape[-2] // 2, corr.shape[-1] // 2
+        c = corr[..., : 2 * hh, : 2 * ww]
+        corr = (c[..., 0::2, 0::2] + c[..., 0::2, 1::2] + c[..., 1::2, 0::2] + c[..., 1::2, 1::2]) / 4
+        pyr.append(corr)
+    return pyr
+
+
+def corr_lookup(pyr, coords, radius=4):
+    """channel lvl*81 + a*9 + b = zero-padded bilinear sample of level lvl at
+    (x/2^lvl + a - r, y/2^lvl + b - r)  (first window axis steps x)."""
+    B, _, h, w = coords.shape
+    r = radius
+    d = 2 * r + 1
+    cx = coords[:, 0].reshape(B * h * w, 1, 1)
+    cy = coords[:, 1].reshape(B * h * w, 1, 1)
+    off = torch.arange(-r, r + 1, dtype=torch.float32)
+    outs = []
+    for lvl, corr in enumerate(pyr):
+        Hl, Wl = corr.shape[-2:]
+        x = cx / 2 ** lvl + off.view(1, d, 1)     # [Q, a, 1]
+        y = cy / 2 ** lvl + off.view(1, 1, d)     # [Q, 1, b]
+        gx = 2 * x / (Wl - 1) - 1
+        gy = 2 * y / (Hl - 1) - 1
+        ix = ((gx + 1) * ((Wl - 1) / 2)).expand(-1, d, d)
+        iy = ((gy + 1) * ((Hl - 1) / 2)).expand(-1, d, d)
+        x0, y0 = ix.floor(), iy.floor()
+        tx, ty = ix - x0, iy - y0
+        x0, y0 = x0.long(), y0.long()
+        flat = corr.reshape(B * h * w, Hl * Wl)
+
+        def tap(yy, xx):
+            ok = ((xx >= 0) & (xx < Wl) & (yy >= 0) & (yy < Hl)).float()
+            idx = (yy.clamp(0, Hl - 1) * Wl + xx.clamp(0, Wl - 1)).reshape(B * h * w, d * d)
+            return flat.gather(1, idx).reshape(B * h * w, d, d) * ok
+
+        s = tap(y0, x0) * ((1 - tx) * (1 - ty)) + tap(y0, x0 + 1) * (tx * (1 - ty)) \
+            + tap(y0 + 1, x0) * ((1 - tx) * ty) + tap(y0 + 1, x0 + 1) * (tx * ty)
+        outs.append(s.reshape(B, h, w, d * d))
+    return torch.cat(outs, dim=-1).permute(0, 3, 1, 2).contiguous()
+
+
+def coords_grid(B, h, w):
+    gy, gx = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+    return torch.stack([gx, gy], 0).float()[None].repeat(B, 1, 1, 1)
+
+
+def update_block(sd, pre, net, inp, corr, emap, flow):
+    """BasicUpdateBlockNoMask: BasicMotionEncoder + SepConvGRU + FlowHead."""
+    e = pre + ".encoder."
+
+    def c(name, x, pad):
+        return conv2d(x, sd[name + ".weight"], sd[name + ".bias"], 1, pad)
+
+    cor = torch.relu(c(e + "convc1", corr, (0, 0)))
+    cor = torch.relu(c(e + "convc2", cor, (1, 1)))
+    ema = torch.relu(c(e + "conve1", emap, (0, 0)))
+    ema = torch.relu(c(e + "conve2", ema, (1, 1)))
+    flo = torch.relu(c(e + "convf1", flow, (3, 3)))
+    flo = torch.relu(c(e + "convf2", flo, (1, 1)))
+    out = torch.relu(c(e + "conv", torch.cat([cor, ema, flo], 1), (1, 1)))
+    x = torch.cat([inp, out, flow], 1)
+    g = pre + ".gru."
+    h = net
+    for sfx, pad in (("1", (0, 2)), ("2", (2, 0))):
+        hx = torch.cat([h, x], 1)
+        z = torch.sigmoid(c(g + "convz" + sfx, hx, pad))
+        r = torch.sigmoid(c(g + "convr" + sfx, hx, pad))
+        q = torch.tanh(c(g + "convq" + sfx, torch.cat([r * h, x], 1), pad))
+        h = (1 - z) * h + z * q
+    fh = pre + ".flow_head."
+    delta = c(fh + "conv2", torch.relu(c(fh + "conv1", h, (1, 1))), (1, 1))
+    return h, delta
+
+
+def eiflow_forward(sd, event_voxel, image1, iters=6, flow_init=None, prefix="event_flownet."):
+    """DCEIFlow.forward (image2 / reversed voxel = None).  Returns dict like the reference."""
+    p = prefix
+    B, _, H, W = image1.shape
+    image1 = 2 * image1 - 1.0
+    image1, ph, pw = image_pad(image1, H, W)
+    event_voxel, _, _ = image_pad(event_voxel, H, W)
+    emap = encoder(sd, p + "enet", event_voxel, "instance")
+    fmap1 = encoder(sd, p + "fnet", image1, "instance")
+    # EIFusion
+    c1 = torch.relu(conv2d(fmap1, sd[p + "fusion.conv1.weight"], sd[p + "fusion.conv1.bias"]))
+    c2 = torch.relu(conv2d(emap, sd[p + "fusion.conv2.weight"], sd[p + "fusion.conv2.bias"]))
+    pf2 = torch.relu(conv2d(torch.cat([c1, c2], 1), sd[p + "fusion.convo.weight"], sd[p + "fusion.convo.bias"], 1, (1, 1))) + fmap1
+    pyr = corr_pyramid(fmap1, pf2)
+    cnet = encoder(sd, p + "cnet", image1, "batch")
+    net, inp = torch.tanh(cnet[:, :128]), torch.relu(cnet[:, 128:])
+    h8, w8 = image1.shape[2] // 8, image1.shape[3] // 8
+    coords0 = coords_grid(B, h8, w8)
+    coords1 = coords_grid(B, h8, w8)
+    if flow_init is not None:
+        coords1 = coords1 + flow_init
+    preds = []
+    flow_up = None
+    for _ in range(iters):
+        corr = corr_lookup(pyr, coords1)
+        flow = coords1 - coords0
+        net, delta = update_block(sd, p + "update_block", net, inp, corr, emap, flow)
+        coords1 = coords1 + delta
+        f = coords1 - coords0
+        up = 8 * interp_bilinear(f, 8 * h8, 8 * w8, align_corners=True)
+        preds.append(up)
+        flow_up = up[..., ph:, pw:]
+    return dict(flow_preds=preds, flow_init=coords1 - coords0, flow_final=flow_up)
+
+
+def eiflow_step(sd, batch_data, states, warp_mode="forward", depth=5, iters=6, gt_flow=None):
+    """DCEIFlowCistaNet.forward (a5).  Mutates states[1] in place like the reference."""
+    bf = eiflow_forward(sd, batch_data["event_voxel"], batch_data["rec_img0"], iters=iters,
+                        flow_init=batch_data.get("flow_init"))
+    flow_final = bf["flow_final"] if gt_flow is None else gt_flow
+    if not flow_final.any():
+        warped_I = batch_data["rec_img0"]
+    else:
+        warped_I = warp(batch_data["rec_img0"], flow_final, warp_mode)
+        if states is not None:
+            H, W = flow_final.shape[-2:]
+            dflow = interp_bilinear(flow_final, H // 2, W // 2, align_corners=True)   # values NOT halved
+            states[1] = warp(states[1], dflow, warp_mode)
+    I_rec, new_states = cista_forward(sd, batch_data["event_voxel"], warped_I, states, depth=depth)
+    return I_rec, bf, new_states

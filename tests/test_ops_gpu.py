@@ -1,0 +1,258 @@
+"""Kernel-level parity: every HIP operator of libcistaflow against a plain PyTorch fp32 CPU
+reference of the same op (tolerance 1e-4 absolute on O(1) data unless stated)."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from cista_flow_amd import lib
+    return lib.load(), lib
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def ref_conv(x, w, b, stride, padT, padL, pad_mode):
+    if pad_mode == 1:
+        xp = F.pad(x, (padL, padL, padT, padT), mode="reflect") if (padT or padL) else x
+    else:
+        xp = F.pad(x, (padL, padL, padT, padT))
+    return F.conv2d(xp, w, b, stride=stride)
+
+
+def run_conv(gpu, x_in, w, b, stride, padT, padL, pad_mode, a_mode, epi, tile, Ho, Wo):
+    L, lib = _lib()
+    B = x_in.shape[0]
+    Cout, Cin, KH, KW = w.shape
+    if a_mode == 2:
+        xin = x_in.contiguous().to(gpu)
+        H, W = x_in.shape[2], x_in.shape[3]
+    else:
+        xin = nhwc(x_in).to(gpu)
+        H, W = x_in.shape[2], x_in.shape[3]
+    wg, bg = w.contiguous().to(gpu), (b.contiguous().to(gpu) if b is not None else None)
+    out = torch.full((B, Ho, Wo, Cout), float("nan"), device=gpu)
+    rc = L.cf_op_conv2d(lib.ptr(xin), B, Cin, H, W, lib.ptr(wg), lib.ptr(bg), Cout, KH, KW, stride, padT, padL,
+                        pad_mode, a_mode, epi, tile, lib.ptr(out), lib.current_stream_ptr())
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    return nchw(out.cpu())
+
+
+CONV_CASES = [
+    # Cin, Cout, KH, KW, stride, padT, padL, pad_mode, tile
+    (64, 64, 3, 3, 1, 1, 1, 1, 0),
+    (64, 64, 3, 3, 2, 1, 1, 1, 0),
+    (192, 256, 3, 3, 1, 1, 1, 1, 0),
+    (128, 64, 3, 3, 1, 1, 1, 1, 0),
+    (64, 128, 3, 3, 1, 1, 1, 1, 0),
+    (256, 128, 3, 3, 1, 1, 1, 1, 0),
+    (16, 96, 3, 3, 1, 1, 1, 0, 0),
+    (64, 96, 1, 1, 2, 0, 0, 0, 0),
+    (96, 96, 3, 3, 2, 1, 1, 0, 0),
+    (384, 128, 1, 5, 1, 0, 2, 0, 0),
+    (384, 128, 5, 1, 1, 2, 0, 0, 0),
+    (128, 256, 3, 3, 1, 1, 1, 0, 0),
+    (256, 2, 3, 3, 1, 1, 1, 0, 0),
+    (64, 1, 3, 3, 1, 1, 1, 1, 0),
+    (320, 126, 3, 3, 1, 1, 1, 0, 0),
+    (336, 256, 1, 1, 1, 0, 0, 0, 0),
+    (128, 576, 1, 1, 1, 0, 0, 0, 0),
+    (64, 128, 3, 3, 1, 1, 1, 1, 1),
+    (64, 128, 3, 3, 1, 1, 1, 1, 2),
+    (64, 128, 3, 3, 1, 1, 1, 1, 3),
+    (64, 128, 3, 3, 1, 1, 1, 1, 4),
+    (64, 128, 3, 3, 1, 1, 1, 1, 5),
+    (64, 128, 3, 3, 1, 1, 1, 1, 6),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_nhwc(gpu, case):
+    Cin, Cout, KH, KW, stride, padT, padL, pad_mode, tile = case
+    g = torch.Generator().manual_seed(hash(case) % 100000)
+    B, H, W = 2, 20, 28
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, KH, KW, generator=g) / (Cin * KH * KW) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = ref_conv(x, w, b, stride, padT, padL, pad_mode)
+    got = run_conv(gpu, x, w, b, stride, padT, padL, pad_mode, 0, 0, tile, ref.shape[2], ref.shape[3])
+    assert got.shape == ref.shape
+    err = (got - ref).abs().max().item()
+    assert err < 1e-4, err
+
+
+@pytest.mark.parametrize("epi", [1, 2, 3])
+def test_conv_epilogue_activation(gpu, epi):
+    g = torch.Generator().manual_seed(7 + epi)
+    x = torch.randn(1, 32, 9, 13, generator=g)
+    w = torch.randn(48, 32, 3, 3, generator=g) / 17.0
+    b = torch.randn(48, generator=g)
+    ref = ref_conv(x, w, b, 1, 1, 1, 1)
+    ref = {1: torch.relu, 2: torch.sigmoid, 3: torch.tanh}[epi](ref)
+    got = run_conv(gpu, x, w, b, 1, 1, 1, 1, 0, epi, 0, 9, 13)
+    assert (got - ref).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("case", [(5, 32, 3, 1, 1, 1), (1, 32, 3, 1, 1, 1), (1, 64, 7, 2, 3, 0), (5, 64, 7, 2, 3, 0),
+                                  (2, 128, 7, 1, 3, 0)])
+def test_conv_gather_small_cin(gpu, case):
+    Cin, Cout, K, stride, pad, pad_mode = case
+    g = torch.Generator().manual_seed(11 + Cin + K)
+    B, H, W = 2, 22, 30
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = ref_conv(x, w, b, stride, pad, pad, pad_mode)
+    got = run_conv(gpu, x, w, b, stride, pad, pad, pad_mode, 2, 0, 0, ref.shape[2], ref.shape[3])
+    assert (got - ref).abs().max().item() < 1e-4
+
+
+def test_conv_fused_upsample(gpu):
+    """UpsampleConvLayer (e2v/base_layers.py:195-212): interpolate x2 (align_corners=False) ->
+    ReflectionPad2d(1) -> conv 3x3 (padding 0) -> relu, with the upsample fused into the A read."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 64, 11, 15, generator=g)
+    w = torch.randn(64, 64, 3, 3, generator=g) / 24.0
+    b = torch.randn(64, generator=g)
+    up = F.interpolate(x, size=[22, 30], mode="bilinear", align_corners=False)
+    ref = torch.relu(F.conv2d(F.pad(up, (1, 1, 1, 1), mode="reflect"), w, b))
+    got = run_conv(gpu, x, w, b, 1, 1, 1, 1, 1, 1, 0, 22, 30)
+    assert (got - ref).abs().max().item() < 1e-4
+
+
+def ref_warp(img, flow, backward):
+    """utils/flow_utils.py:83-120 / 153-190 restated with F.grid_sample."""
+    B, C, H, W = img.shape
+    gy, gx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    u, v = flow[:, 0], flow[:, 1]
+    x = gx[None].float() + u if backward else gx[None].float() - u
+    y = gy[None].float() + v if backward else gy[None].float() - v
+    x = 2 * (x / W - 0.5)
+    y = 2 * (y / H - 0.5)
+    grid = torch.stack((x, y), dim=3)
+    return F.grid_sample(img, grid, align_corners=True, padding_mode="reflection")
+
+
+@pytest.mark.parametrize("C_,backward", [(1, 0), (1, 1), (128, 0), (6, 0)])
+def test_warp(gpu, C_, backward):
+    from cista_flow_amd import lib
+    L = lib.load()
+    g = torch.Generator().manual_seed(3 + C_)
+    B, H, W = 2, 18, 26
+    img = torch.randn(B, C_, H, W, generator=g)
+    flow = torch.randn(B, 2, H, W, generator=g) * 6.0   # big enough to hit the reflection branch
+    flow[0, :, :3] = 0.0
+    ref = ref_warp(img, flow, backward)
+    h = lib.Handle(lib.CF_MODE_CISTA, B, 2 * H, 2 * W)
+    xin = nhwc(img).to(gpu)
+    fl = flow.to(gpu)
+    out = torch.full_like(xin, float("nan"))
+    h.check(L.cf_warp(h.h, lib.ptr(xin), lib.ptr(fl), lib.ptr(out), B, C_, H, W, H, W, backward,
+                      lib.current_stream_ptr()), "cf_warp")
+    torch.cuda.synchronize()
+    got = nchw(out.cpu())
+    assert (got - ref).abs().max().item() < 2e-5
+
+
+def test_warp_with_downsampled_flow(gpu):
+    """states[1] warp: interpolate(flow, 0.5, bilinear, align_corners=True) without halving values
+    (e2v/e2v_model.py:190-191)."""
+    from cista_flow_amd import lib
+    L = lib.load()
+    g = torch.Generator().manual_seed(17)
+    B, H, W, C_ = 2, 20, 28, 128
+    z = torch.randn(B, C_, H // 2, W // 2, generator=g)
+    flow = torch.randn(B, 2, H, W, generator=g) * 3.0
+    dflow = F.interpolate(flow, scale_factor=0.5, mode="bilinear", align_corners=True)
+    ref = ref_warp(z, dflow, 0)
+    h = lib.Handle(lib.CF_MODE_CISTA, B, H, W)
+    xin = nhwc(z).to(gpu)
+    out = torch.full_like(xin, float("nan"))
+    h.check(L.cf_warp(h.h, lib.ptr(xin), lib.ptr(flow.to(gpu)), lib.ptr(out), B, C_, H // 2, W // 2, H, W, 0,
+                      lib.current_stream_ptr()), "cf_warp")
+    torch.cuda.synchronize()
+    # tolerance: ~1e-5 px of coordinate rounding (two chained interpolations) x O(1) image gradient
+    assert (nchw(out.cpu()) - ref).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("C_", [64, 96, 128])
+def test_instance_norm_relu(gpu, C_):
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(C_)
+    B, H, W = 2, 24, 40
+    x = torch.randn(B, C_, H, W, generator=g) * 3.0 + 1.5
+    ref = torch.relu(F.instance_norm(x, eps=1e-5))
+    xin = nhwc(x).to(gpu)
+    out = torch.full_like(xin, float("nan"))
+    assert L.cf_op_instance_norm_relu(lib.ptr(xin), lib.ptr(out), B, C_, H, W, 1e-5, lib.current_stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert (nchw(out.cpu()) - ref).abs().max().item() < 2e-5
+
+
+def ref_corr_lookup(fmap1, fmap2, coords, radius=4, levels=4):
+    """DCEIFlow/core/corr/raft_corr.py:15-65 + DCEIFlow/utils/sample_utils.py:38-52 restated."""
+    B, D, h, w = fmap1.shape
+    corr = torch.matmul(fmap1.view(B, D, h * w).transpose(1, 2), fmap2.view(B, D, h * w))
+    corr = corr.view(B * h * w, 1, h, w) / torch.sqrt(torch.tensor(D).float())
+    pyr = [corr]
+    for _ in range(levels - 1):
+        corr = F.avg_pool2d(corr, 2, stride=2)
+        pyr.append(corr)
+    r = radius
+    c = coords.permute(0, 2, 3, 1)
+    outs = []
+    for i in range(levels):
+        cr = pyr[i]
+        dx = torch.linspace(-r, r, 2 * r + 1)
+        dy = torch.linspace(-r, r, 2 * r + 1)
+        delta = torch.stack(torch.meshgrid(dy, dx, indexing="ij"), axis=-1)
+        cl = c.reshape(B * h * w, 1, 1, 2) / 2 ** i + delta.view(1, 2 * r + 1, 2 * r + 1, 2)
+        Hh, Ww = cr.shape[-2:]
+        xg, yg = cl.split([1, 1], dim=-1)
+        xg = 2 * xg / (Ww - 1) - 1
+        yg = 2 * yg / (Hh - 1) - 1
+        s = F.grid_sample(cr, torch.cat([xg, yg], dim=-1), align_corners=True)
+        outs.append(s.view(B, h, w, -1))
+    return torch.cat(outs, dim=-1).permute(0, 3, 1, 2).contiguous()
+
+
+def test_corr_lookup(gpu):
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(23)
+    B, D, h, w = 2, 64, 16, 24
+    f1 = torch.randn(B, D, h, w, generator=g)
+    f2 = torch.randn(B, D, h, w, generator=g)
+    gy, gx = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+    coords = torch.stack([gx, gy], 0)[None].float().repeat(B, 1, 1, 1) + torch.randn(B, 2, h, w, generator=g) * 2.5
+    ref = ref_corr_lookup(f1, f2, coords)
+    out = torch.full((B, h, w, 324), float("nan"), device=gpu)
+    rc = L.cf_op_corr_lookup(lib.ptr(nhwc(f1).to(gpu)), lib.ptr(nhwc(f2).to(gpu)), lib.ptr(coords.to(gpu)),
+                             lib.ptr(out), B, D, h, w, lib.current_stream_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    err = (nchw(out.cpu()) - ref).abs().max().item()
+    assert err < 2e-4, err
+
+
+def test_layout_roundtrip(gpu):
+    L, lib = _lib()
+    x = torch.randn(3, 37, 5, 11)
+    xg = x.to(gpu)
+    y = torch.empty(3, 5, 11, 37, device=gpu)
+    assert L.cf_op_nchw_to_nhwc(lib.ptr(xg), lib.ptr(y), 3, 37, 5, 11, lib.current_stream_ptr()) == 0
+    z = torch.empty_like(xg)
+    assert L.cf_op_nhwc_to_nchw(lib.ptr(y), lib.ptr(z), 3, 37, 5, 11, lib.current_stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y.cpu(), nhwc(x))
+    assert torch.equal(z.cpu(), x)
