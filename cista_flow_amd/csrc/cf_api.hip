@@ -68,7 +68,7 @@ struct cf_handle {
     std::map<std::string, PackedConv> conv;
     float* lambda = nullptr;   // [2*base]
     std::vector<void*> owned;  // hipMalloc'ed weight buffers
-    bool finalized = false;
+    bool finalized = false, has_cista = false, has_flow = false;
 
     // geometry
     int B = 0, H = 0, W = 0, h = 0, w = 0;       // full / half resolution
@@ -280,10 +280,10 @@ static int pack_conv(cf_handle* h, const std::string& key, const std::string& pr
     return CF_OK;
 }
 
-static int pack_encoder(cf_handle* h, const std::string& pre, bool bn, hipStream_t st) {
+static int pack_encoder(cf_handle* h, const std::string& pre, const std::string& keypre, bool bn, hipStream_t st) {
     int rc;
     auto P = [&](const std::string& key, const std::string& name, bool gather, const std::string& bnname) -> int {
-        return pack_conv(h, pre + "." + key, pre + "." + name, gather, 0, 0, bn ? pre + "." + bnname : std::string(), st);
+        return pack_conv(h, keypre + "." + key, pre + "." + name, gather, 0, 0, bn ? pre + "." + bnname : std::string(), st);
     };
     if ((rc = P("conv1", "conv1", true, "norm1"))) return rc;
     for (int L = 1; L <= 3; ++L) {
@@ -295,7 +295,7 @@ static int pack_encoder(cf_handle* h, const std::string& pre, bool bn, hipStream
                 if ((rc = P(b + ".downsample.0", b + ".downsample.0", false, b + ".downsample.1"))) return rc;
         }
     }
-    return pack_conv(h, pre + ".conv2", pre + ".conv2", false, 0, 0, "", st);
+    return pack_conv(h, keypre + ".conv2", pre + ".conv2", false, 0, 0, "", st);
 }
 
 extern "C" int cf_load_weights(cf_handle* h, const char* name, const void* dev_ptr, const int64_t* shape, int ndim) {
@@ -318,35 +318,48 @@ extern "C" int cf_finalize_weights(cf_handle* h, void* stream) {
     h->conv.clear();
     h->lambda = nullptr;
     int rc;
-    const std::string cn = (h->cfg.mode == CF_MODE_CISTA && !find_raw(h, "cista_net.We.conv2d.weight")) ? "" : "cista_net.";
-    auto C = [&](const std::string& key, const std::string& name, bool gather) -> int {
-        return pack_conv(h, "cista." + key, cn + name, gather, 0, 0, "", st);
-    };
-    // CistaLSTCNet (e2v_model.py:21-44); lista_blocks.0..4 alias one IstaBlock (:34-35)
-    if ((rc = C("We", "We.conv2d", true))) return rc;
-    if ((rc = C("Wi", "Wi.conv2d", true))) return rc;
-    if ((rc = C("W0", "W0.conv2d", false))) return rc;
-    if ((rc = C("gates", "P0.gates", false))) return rc;
-    if ((rc = C("out_gates", "P0.out_gates", false))) return rc;
-    if ((rc = C("P0", "P0.P0", false))) return rc;
-    if ((rc = C("D", "lista_blocks.0.D.conv2d", false))) return rc;
-    if ((rc = C("P", "lista_blocks.0.P.conv2d", false))) return rc;
-    if ((rc = C("Dg", "Dg.conv.conv2d", false))) return rc;
-    if ((rc = C("Gates", "Dg.recurrent_block.Gates", false))) return rc;
-    if ((rc = C("upsamp", "upsamp_conv.conv2d", false))) return rc;
-    if ((rc = C("final", "final_conv.conv2d", false))) return rc;
-    {
+    h->has_cista = h->has_flow = false;
+    // the state_dict may be that of the combined net ("cista_net." / "event_flownet." prefixes) or
+    // of a stand-alone CistaLSTCNet / DCEIFlow (no prefix)
+    std::string cn, fn;
+    bool got_cista = false, got_flow = false;
+    if (find_raw(h, "cista_net.We.conv2d.weight")) { cn = "cista_net."; got_cista = true; }
+    else if (find_raw(h, "We.conv2d.weight")) { cn = ""; got_cista = true; }
+    if (find_raw(h, "event_flownet.fnet.conv1.weight")) { fn = "event_flownet."; got_flow = true; }
+    else if (find_raw(h, "fnet.conv1.weight")) { fn = ""; got_flow = true; }
+    if (!got_cista && !got_flow) return h->fail(CF_ERR_WEIGHT, "cf_finalize_weights: no known weights were announced");
+    if (got_cista) {
+        auto C = [&](const std::string& key, const std::string& name, bool gather) -> int {
+            return pack_conv(h, "cista." + key, cn + name, gather, 0, 0, "", st);
+        };
+        // CistaLSTCNet (e2v_model.py:21-44); lista_blocks.0..4 alias one IstaBlock (:34-35)
+        if ((rc = C("We", "We.conv2d", true))) return rc;
+        if ((rc = C("Wi", "Wi.conv2d", true))) return rc;
+        if ((rc = C("W0", "W0.conv2d", false))) return rc;
+        if ((rc = C("gates", "P0.gates", false))) return rc;
+        if ((rc = C("out_gates", "P0.out_gates", false))) return rc;
+        if ((rc = C("P0", "P0.P0", false))) return rc;
+        if ((rc = C("D", "lista_blocks.0.D.conv2d", false))) return rc;
+        if ((rc = C("P", "lista_blocks.0.P.conv2d", false))) return rc;
+        if ((rc = C("Dg", "Dg.conv.conv2d", false))) return rc;
+        if ((rc = C("Gates", "Dg.recurrent_block.Gates", false))) return rc;
+        if ((rc = C("upsamp", "upsamp_conv.conv2d", false))) return rc;
+        if ((rc = C("final", "final_conv.conv2d", false))) return rc;
         const RawWeight* lam = find_raw(h, cn + "lista_blocks.0.Lambda");
         if (!lam || lam->numel() != 2 * h->bc) return h->fail(CF_ERR_WEIGHT, "missing/bad Lambda");
         CF_HIP(h, hipMalloc(reinterpret_cast<void**>(&h->lambda), lam->numel() * sizeof(float)));
         h->owned.push_back(h->lambda);
         CF_HIP(h, hipMemcpyAsync(h->lambda, lam->ptr, lam->numel() * sizeof(float), hipMemcpyDeviceToDevice, st));
+        const PackedConv& we = h->conv["cista.We"];
+        if (we.cin != h->cfg.num_bins || we.cout != h->bc / 2 || h->conv["cista.P0"].cout != 2 * h->bc)
+            return h->fail(CF_ERR_WEIGHT, "CISTA weights do not match num_bins/base_channels of the handle");
+        h->has_cista = true;
     }
-    if (h->cfg.mode == CF_MODE_EIFLOW) {
-        const std::string f = "event_flownet.";
-        if ((rc = pack_encoder(h, f + "fnet", false, st))) return rc;
-        if ((rc = pack_encoder(h, f + "enet", false, st))) return rc;
-        if ((rc = pack_encoder(h, f + "cnet", true, st))) return rc;
+    if (got_flow && h->cfg.mode == CF_MODE_EIFLOW) {
+        const std::string& f = fn;
+        if ((rc = pack_encoder(h, f + "fnet", "event_flownet.fnet", false, st))) return rc;
+        if ((rc = pack_encoder(h, f + "enet", "event_flownet.enet", false, st))) return rc;
+        if ((rc = pack_encoder(h, f + "cnet", "event_flownet.cnet", true, st))) return rc;
         auto F = [&](const std::string& key, const std::string& name, bool gather) -> int {
             return pack_conv(h, key, f + name, gather, 0, 0, "", st);
         };
@@ -372,6 +385,8 @@ extern "C" int cf_finalize_weights(cf_handle* h, void* stream) {
         if ((rc = F("fh.conv1", "update_block.flow_head.conv1", false))) return rc;
         if ((rc = F("fh.conv2", "update_block.flow_head.conv2", false))) return rc;
         if (h->conv["convc1"].cin_pad != cf_handle::CORR_LD) return h->fail(CF_ERR_WEIGHT, "convc1 expects 324 input channels");
+        if (h->conv["event_flownet.enet.conv1"].cin != h->cfg.num_bins) return h->fail(CF_ERR_WEIGHT, "enet.conv1 does not match num_bins");
+        h->has_flow = true;
     }
     // the announced pointers may die after this call: drain the packing kernels
     CF_HIP(h, hipStreamSynchronize(st));
@@ -413,9 +428,9 @@ extern "C" int cf_create(cf_handle** out, const cf_config* cfg) {
     h->Hp = h->H + h->padH; h->Wp = h->W + h->padW;
     h->H1 = h->Hp / 2; h->W1 = h->Wp / 2; h->H2 = h->Hp / 4; h->W2 = h->Wp / 4; h->h8 = h->Hp / 8; h->w8 = h->Wp / 8;
     h->N = h->h8 * h->w8;
-    if (cfg->mode == CF_MODE_EIFLOW && (h->h8 < 8 || h->w8 < 8)) {
+    if (cfg->mode == CF_MODE_EIFLOW && (h->h8 < 16 || h->w8 < 16)) {
         delete h;
-        return bad("cf_create: padded image must be >= 64x64 for the 4-level correlation pyramid");
+        return bad("cf_create: padded image must be >= 128x128 (4th correlation pyramid level >= 2x2)");
     }
     if (hipSetDevice(cfg->device) != hipSuccess) {
         delete h;
@@ -461,10 +476,12 @@ extern "C" size_t cf_workspace_bytes(const cf_handle* h) { return h ? h->arena.c
 // ---------------------------------------------------------------------------------------------
 extern "C" int cf_warp(cf_handle* h, const float* img, const float* flow, float* out, int B, int C, int H, int W, int Hf,
                        int Wf, int mode, void* stream) {
-    if (!h) return CF_ERR_ARG;
-    if (!img || !flow || !out || B < 1 || C < 1 || H < 2 || W < 2) return h->fail(CF_ERR_ARG, "cf_warp: bad argument");
-    CF_HIP(h, launch_warp(img, C, (long)H * W * C, flow, Hf, Wf, out, C, (long)H * W * C, B, C, H, W,
-                          mode == CF_WARP_BACKWARD ? 1 : 0, nullptr, static_cast<hipStream_t>(stream)));
+    // h may be NULL: the warp needs no workspace or weights
+    auto fail = [&](int code, const char* msg) { return h ? h->fail(code, msg) : code; };
+    if (!img || !flow || !out || B < 1 || C < 1 || H < 2 || W < 2 || Hf < 2 || Wf < 2) return fail(CF_ERR_ARG, "cf_warp: bad argument");
+    hipError_t e = launch_warp(img, C, (long)H * W * C, flow, Hf, Wf, out, C, (long)H * W * C, B, C, H, W,
+                               mode == CF_WARP_BACKWARD ? 1 : 0, nullptr, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return fail(CF_ERR_HIP, hipGetErrorString(e));
     return CF_OK;
 }
 
@@ -552,7 +569,7 @@ extern "C" int cf_cista_forward(cf_handle* h, const float* ev, const float* img,
                                 const float* h_prev, const float* cc_prev, float* I_out, float* c_out, float* z_out,
                                 float* h_out, float* cc_out, void* stream) {
     if (!h) return CF_ERR_ARG;
-    if (!h->finalized) return h->fail(CF_ERR_STATE, "cf_cista_forward: weights not finalised");
+    if (!h->finalized || !h->has_cista) return h->fail(CF_ERR_STATE, "cf_cista_forward: CISTA weights not finalised");
     if (!ev || !img || !I_out || !c_out || !z_out || !h_out || !cc_out) return h->fail(CF_ERR_ARG, "cf_cista_forward: null pointer");
     if ((h_prev == nullptr) != (cc_prev == nullptr)) return h->fail(CF_ERR_ARG, "cf_cista_forward: h_prev/cc_prev must come together");
     CF_HIP(h, hipSetDevice(h->cfg.device));
@@ -750,7 +767,7 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
 extern "C" int cf_flow_forward(cf_handle* h, const float* in0, const float* in1, const float* flow_init, float* flow_final,
                                float* flow_low, float* flow_preds, void* stream) {
     if (!h) return CF_ERR_ARG;
-    if (!h->finalized) return h->fail(CF_ERR_STATE, "cf_flow_forward: weights not finalised");
+    if (!h->finalized || !h->has_flow) return h->fail(CF_ERR_STATE, "cf_flow_forward: flow-net weights not finalised");
     if (h->cfg.mode != CF_MODE_EIFLOW) return h->fail(CF_ERR_UNSUPPORTED, "cf_flow_forward: handle has no flow network");
     if (!in0 || !in1 || !flow_final) return h->fail(CF_ERR_ARG, "cf_flow_forward: null pointer");
     CF_HIP(h, hipSetDevice(h->cfg.device));
@@ -765,7 +782,7 @@ extern "C" int cf_step(cf_handle* h, const float* in0, const float* in1, const f
                        const float* cc_prev, float* I_out, float* flow_final, float* flow_low, float* flow_preds,
                        float* z_warped_out, float* c_out, float* z_out, float* h_out, float* cc_out, void* stream) {
     if (!h) return CF_ERR_ARG;
-    if (!h->finalized) return h->fail(CF_ERR_STATE, "cf_step: weights not finalised");
+    if (!h->finalized || !h->has_cista || !h->has_flow) return h->fail(CF_ERR_STATE, "cf_step: weights not finalised");
     if (h->cfg.mode != CF_MODE_EIFLOW) return h->fail(CF_ERR_UNSUPPORTED, "cf_step: mode not built yet");
     if (!in0 || !in1 || !rec_img0 || !I_out || !flow_final || !c_out || !z_out || !h_out || !cc_out)
         return h->fail(CF_ERR_ARG, "cf_step: null pointer");
@@ -862,7 +879,7 @@ extern "C" int cf_op_instance_norm_relu(const float* x, float* out, int B, int C
 extern "C" int cf_op_corr_lookup(const float* fmap1, const float* fmap2, const float* coords, float* out, int B, int D, int hh,
                                  int ww, void* stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (!fmap1 || !fmap2 || !coords || !out || (D % 16) != 0 || hh < 8 || ww < 8) return CF_ERR_ARG;
+    if (!fmap1 || !fmap2 || !coords || !out || (D % 16) != 0 || hh < 16 || ww < 16) return CF_ERR_ARG;
     const long N = (long)hh * ww;
     TmpBuf lv[4], feat;
     int lh[4], lw[4];

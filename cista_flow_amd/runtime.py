@@ -1,0 +1,57 @@
+"""Handle cache shared by the nn.Module shells: one cf_handle per (batch, device), weights re-packed
+whenever the module's parameters change (load_state_dict, .to(), in-place edits)."""
+import torch
+
+from . import lib as _lib
+
+
+class HipBackend(object):
+    def __init__(self, module, mode, image_dim, num_bins=5, base_channels=64, depth=5, iters=6, warp_mode='forward'):
+        self.module = module
+        self.mode = mode
+        self.image_dim = (int(image_dim[0]), int(image_dim[1]))
+        self.kw = dict(num_bins=num_bins, base_channels=base_channels, depth=depth, iters=iters,
+                       warp_mode=_lib.CF_WARP_FORWARD if warp_mode == 'forward' else _lib.CF_WARP_BACKWARD)
+        self.handles = {}     # (B, device index) -> [Handle, weight signature]
+
+    def _signature(self):
+        sig = []
+        for t in self.module.state_dict(keep_vars=True).values():
+            sig.append((t.data_ptr(), t._version))
+        return tuple(sig)
+
+    def get(self, batch, device):
+        if device.type != 'cuda':
+            raise RuntimeError("cista_flow_amd runs on the GPU only (got device %s); move the model and inputs with "
+                               ".to('cuda')" % device)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        key = (int(batch), idx)
+        ent = self.handles.get(key)
+        if ent is None:
+            h = _lib.Handle(self.mode, int(batch), self.image_dim[0], self.image_dim[1], device=idx, **self.kw)
+            ent = [h, None]
+            self.handles[key] = ent
+        sig = self._signature()
+        if ent[1] != sig:
+            sd = self.module.state_dict()
+            for k, v in sd.items():
+                if isinstance(v, torch.Tensor) and v.is_floating_point() and (not v.is_cuda or v.device.index != idx):
+                    raise RuntimeError("parameter %s lives on %s but the input is on cuda:%d" % (k, v.device, idx))
+            ent[0].load_state_dict(sd)
+            ent[1] = sig
+        return ent[0]
+
+    def clear(self):
+        for h, _ in self.handles.values():
+            h.close()
+        self.handles = {}
+
+
+def nhwc_state(t, name, shape):
+    """A recurrent state as NHWC memory: channels_last tensors pass through untouched."""
+    _lib.check_f32_cuda(t, name, shape)
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def empty_nhwc(B, C, H, W, device):
+    return torch.empty((B, C, H, W), dtype=torch.float32, device=device, memory_format=torch.channels_last)

@@ -178,8 +178,9 @@ def test_warp_with_downsampled_flow(gpu):
     ref = ref_warp(z, dflow, 0)
     h = lib.Handle(lib.CF_MODE_CISTA, B, H, W)
     xin = nhwc(z).to(gpu)
+    fl = flow.to(gpu)
     out = torch.full_like(xin, float("nan"))
-    h.check(L.cf_warp(h.h, lib.ptr(xin), lib.ptr(flow.to(gpu)), lib.ptr(out), B, C_, H // 2, W // 2, H, W, 0,
+    h.check(L.cf_warp(h.h, lib.ptr(xin), lib.ptr(fl), lib.ptr(out), B, C_, H // 2, W // 2, H, W, 0,
                       lib.current_stream_ptr()), "cf_warp")
     torch.cuda.synchronize()
     # tolerance: ~1e-5 px of coordinate rounding (two chained interpolations) x O(1) image gradient
@@ -237,8 +238,8 @@ def test_corr_lookup(gpu):
     coords = torch.stack([gx, gy], 0)[None].float().repeat(B, 1, 1, 1) + torch.randn(B, 2, h, w, generator=g) * 2.5
     ref = ref_corr_lookup(f1, f2, coords)
     out = torch.full((B, h, w, 324), float("nan"), device=gpu)
-    rc = L.cf_op_corr_lookup(lib.ptr(nhwc(f1).to(gpu)), lib.ptr(nhwc(f2).to(gpu)), lib.ptr(coords.to(gpu)),
-                             lib.ptr(out), B, D, h, w, lib.current_stream_ptr())
+    f1g, f2g, cg = nhwc(f1).to(gpu), nhwc(f2).to(gpu), coords.to(gpu)   # keep alive across the async call
+    rc = L.cf_op_corr_lookup(lib.ptr(f1g), lib.ptr(f2g), lib.ptr(cg), lib.ptr(out), B, D, h, w, lib.current_stream_ptr())
     assert rc == 0
     torch.cuda.synchronize()
     err = (nchw(out.cpu()) - ref).abs().max().item()

@@ -1,0 +1,87 @@
+"""The CPU oracle (oracle/cista_oracle.py) against golden vectors produced by running the reference itself
+(tools/gen_golden.py).  This is what pins the oracle; the GPU parity tests then compare HIP vs oracle/goldens.
+Tolerance: 1e-5 relative to tensor scale (same fp32 arithmetic, different summation order only)."""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import golden_util as gu          # noqa: E402
+import weights_util as wu         # noqa: E402
+from oracle import cista_oracle as orc   # noqa: E402
+
+TOL = 1e-5
+
+
+def test_warp_golden():
+    g = gu.load("warp.npz")
+    for i in range(4):
+        img, flow = torch.from_numpy(g["img_%d" % i]), torch.from_numpy(g["flow_%d" % i])
+        mode = "forward" if int(g["mode_%d" % i][0]) == 0 else "backward"
+        out = orc.warp(img, flow, mode)
+        assert gu.rel_err(out, g["out_%d" % i]) < TOL
+
+
+def test_zero_flow_warp_is_not_identity():
+    g = gu.load("warp.npz")
+    img = torch.from_numpy(g["img_3"])
+    out = torch.from_numpy(g["out_3"])      # reference output for an all-zero flow
+    assert (out - img).abs().max() > 0.1    # the W-not-(W-1) quirk (flow_utils.py:114-115)
+
+
+def test_cista_golden():
+    g = gu.load("cista_36x52.npz")
+    H, W, B, frames, seed = [int(v) for v in g["meta"]]
+    sd = wu.make_state_dict(gu.layout("cista_state_dict_layout.json"), seed)
+    states, prev = None, torch.zeros(B, 1, H, W)
+    for t in range(frames):
+        ev = torch.from_numpy(g["ev_%d" % t])
+        assert torch.equal(ev, wu.synth_events(B, 5, H, W, seed * 1000 + t))
+        I, states = orc.cista_forward(sd, ev, prev, states, prefix="")
+        assert gu.rel_err(I, g["I_%d" % t]) < TOL
+        assert gu.rel_err(gu.sub(states[0], 2, 1, 2), g["c_%d" % t]) < TOL
+        assert gu.rel_err(gu.sub(states[1], 2, 1, 2), g["z_%d" % t]) < TOL
+        assert gu.rel_err(gu.sub(states[2][0], 2, 1, 2), g["h_%d" % t]) < TOL
+        assert gu.rel_err(gu.sub(states[2][1], 2, 1, 2), g["cc_%d" % t]) < TOL
+        prev = I.clone()
+
+
+@pytest.mark.parametrize("name,mode", [("eiflow_100x124.npz", "forward"), ("eiflow_128x136_bw.npz", "backward"),
+                                       ("eiflow_180x240.npz", "forward")])
+def test_eiflow_golden(name, mode):
+    g = gu.load(name)
+    H, W, B, frames, seed = [int(v) for v in g["meta"]]
+    sd = wu.make_state_dict(gu.layout("eiflow_state_dict_layout.json"), seed)
+    states, prev = None, torch.zeros(B, 1, H, W)
+    for t in range(frames):
+        ev = torch.from_numpy(g["ev_%d" % t])
+        I, bf, states = orc.eiflow_step(sd, {"event_voxel": ev, "rec_img0": prev}, states, warp_mode=mode)
+        # flow through 6 GRU iterations and the recurrence: 5e-5 of the tensor scale
+        assert gu.rel_err(bf["flow_final"], g["flow_%d" % t]) < 5e-5, t
+        assert gu.rel_err(bf["flow_init"], g["flowlow_%d" % t]) < 5e-5, t
+        assert gu.rel_err(I, g["I_%d" % t]) < 5e-5, t
+        assert gu.rel_err(gu.sub(states[1]), g["z_%d" % t]) < 5e-5, t
+        assert gu.rel_err(gu.sub(states[0]), g["c_%d" % t]) < 5e-5, t
+        assert gu.rel_err(gu.sub(states[2][0]), g["h_%d" % t]) < 5e-5, t
+        assert gu.rel_err(gu.sub(states[2][1]), g["cc_%d" % t]) < 5e-5, t
+        if "preds0_%d" % t in g:
+            assert gu.rel_err(bf["flow_preds"][0], g["preds0_%d" % t]) < 5e-5
+        prev = I.clone()
+
+
+def test_state_dict_layout_matches_reference():
+    """The shell modules must expose the reference's state_dict keys, shapes and order (262 entries)."""
+    import argparse
+    from cista_flow_amd.e2v.e2v_model import CistaLSTCNet, DCEIFlowCistaNet
+    a = argparse.Namespace(image_dim=[180, 240], num_bins=5, warp_mode='forward', base_channels=64, depth=5, ds=8, is_bi=False)
+    m = DCEIFlowCistaNet(a)
+    assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == gu.layout("eiflow_state_dict_layout.json")
+    c = CistaLSTCNet([180, 240])
+    assert [(k, tuple(v.shape)) for k, v in c.state_dict().items()] == gu.layout("cista_state_dict_layout.json")
+    # the five lista blocks alias one storage and survive a strict load
+    sd = wu.make_state_dict(gu.layout("eiflow_state_dict_layout.json"), 5)
+    m.load_state_dict(sd, strict=True)
+    blocks = m.cista_net.lista_blocks
+    assert all(blocks[i].Lambda.data_ptr() == blocks[0].Lambda.data_ptr() for i in range(5))

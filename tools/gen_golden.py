@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by IMPORTING AND RUNNING THE REFERENCE (/root/reference) on CPU.
+
+Runs only in the build container (the reference never travels to the GPU box; only these small
+input/output vectors do).  Two unused top-level imports of the reference are stubbed exactly as
+SURVEY.md section 8c records: `cv2` (pulled by utils.data_io, unused on this path) and `omegaconf`
+(IDNet config only).  Weights are the seeded synthetic ones of tests/weights_util.py.
+
+    python tools/gen_golden.py            # rewrites every fixture
+"""
+import argparse
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+REF = "/root/reference"
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    sys.modules["cv2"] = types.ModuleType("cv2")
+    om = types.ModuleType("omegaconf")
+
+    class OmegaConf:
+        @staticmethod
+        def create(d):
+            return types.SimpleNamespace(**d)
+
+    om.OmegaConf = OmegaConf
+    sys.modules["omegaconf"] = om
+    import e2v.e2v_model as ref_model          # noqa: E402
+    import utils.flow_utils as ref_flow        # noqa: E402
+    return ref_model, ref_flow
+
+
+def ns(H, W, warp_mode="forward"):
+    return argparse.Namespace(image_dim=[H, W], num_bins=5, warp_mode=warp_mode, base_channels=64, depth=5, ds=8,
+                              is_bi=False)
+
+
+def sub(t, cs=4, ys=3, xs=3):
+    """strided probe of a [B,C,h,w] state (keeps fixtures small)."""
+    return t[:, ::cs, ::ys, ::xs].contiguous().numpy()
+
+
+def run_eiflow(ref_model, H, W, B, frames, seed, warp_mode, name, keep_inter=False):
+    from weights_util import fill_module, synth_events
+    torch.manual_seed(0)
+    model = ref_model.DCEIFlowCistaNet(ns(H, W, warp_mode)).eval()
+    fill_module(model, seed)
+    out = {"meta": np.array([H, W, B, frames, seed], dtype=np.int64)}
+    states = None
+    prev = torch.zeros(B, 1, H, W)
+    with torch.no_grad():
+        for t in range(frames):
+            ev = synth_events(B, 5, H, W, seed * 1000 + t)
+            I, bf, states = model({"event_voxel": ev, "rec_img0": prev}, states, {})
+            out["ev_%d" % t] = ev.numpy()
+            out["I_%d" % t] = I.numpy()
+            out["flow_%d" % t] = bf["flow_final"].numpy()
+            out["flowlow_%d" % t] = bf["flow_init"].numpy()
+            out["c_%d" % t] = sub(states[0])
+            out["z_%d" % t] = sub(states[1])
+            out["h_%d" % t] = sub(states[2][0])
+            out["cc_%d" % t] = sub(states[2][1])
+            if keep_inter and t == 0:
+                out["preds0_0"] = bf["flow_preds"][0].numpy()
+            prev = I.clone()
+    np.savez_compressed(os.path.join(GOLD, name), **out)
+    print(name, {k: v.shape for k, v in out.items() if k.endswith("_0")})
+    return model
+
+
+def run_cista(ref_model, H, W, B, frames, seed, name):
+    from weights_util import fill_module, synth_events
+    torch.manual_seed(0)
+    net = ref_model.CistaLSTCNet([H, W]).eval()
+    fill_module(net, seed)
+    out = {"meta": np.array([H, W, B, frames, seed], dtype=np.int64)}
+    states = None
+    prev = torch.zeros(B, 1, H, W)
+    with torch.no_grad():
+        for t in range(frames):
+            ev = synth_events(B, 5, H, W, seed * 1000 + t)
+            I, states = net(ev, prev, states)
+            out["ev_%d" % t] = ev.numpy()
+            out["I_%d" % t] = I.numpy()
+            out["c_%d" % t] = sub(states[0], 2, 1, 2)
+            out["z_%d" % t] = sub(states[1], 2, 1, 2)
+            out["h_%d" % t] = sub(states[2][0], 2, 1, 2)
+            out["cc_%d" % t] = sub(states[2][1], 2, 1, 2)
+            prev = I.clone()
+    np.savez_compressed(os.path.join(GOLD, name), **out)
+    print(name)
+
+
+def run_warp(ref_flow, name):
+    g = torch.Generator().manual_seed(99)
+    out = {}
+    for i, (C, H, W, mode, scale) in enumerate([(1, 20, 28, "forward", 5.0), (1, 20, 28, "backward", 5.0),
+                                                  (16, 10, 14, "forward", 9.0), (3, 12, 18, "forward", 0.0)]):
+        img = torch.randn(2, C, H, W, generator=g)
+        flow = torch.randn(2, 2, H, W, generator=g) * scale
+        fw = ref_flow.FrameWarp(mode)
+        res = fw.warp_frame(img, flow)
+        out["img_%d" % i] = img.numpy()
+        out["flow_%d" % i] = flow.numpy()
+        out["out_%d" % i] = res.numpy()
+        out["mode_%d" % i] = np.array([0 if mode == "forward" else 1])
+    np.savez_compressed(os.path.join(GOLD, name), **out)
+    print(name)
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    ref_model, ref_flow = import_reference()
+    # state_dict layout golden (keys, shapes, order)
+    m = ref_model.DCEIFlowCistaNet(ns(180, 240)).eval()
+    with open(os.path.join(GOLD, "eiflow_state_dict_layout.json"), "w") as f:
+        json.dump([[k, list(v.shape)] for k, v in m.state_dict().items()], f)
+    c = ref_model.CistaLSTCNet([180, 240])
+    with open(os.path.join(GOLD, "cista_state_dict_layout.json"), "w") as f:
+        json.dump([[k, list(v.shape)] for k, v in c.state_dict().items()], f)
+    run_warp(ref_flow, "warp.npz")
+    run_cista(ref_model, 36, 52, 2, 3, 11, "cista_36x52.npz")
+    # 100x124 pads (top 28 / left 4) to 128x128: the smallest padded size whose 4th pyramid level is still
+    # 2x2 (a 1x1 level makes bilinear_sampler divide by W-1 = 0 and the reference itself returns NaN)
+    run_eiflow(ref_model, 100, 124, 2, 4, 21, "forward", "eiflow_100x124.npz", keep_inter=True)
+    run_eiflow(ref_model, 128, 136, 1, 2, 22, "backward", "eiflow_128x136_bw.npz")
+    run_eiflow(ref_model, 180, 240, 1, 2, 23, "forward", "eiflow_180x240.npz")
+
+
+if __name__ == "__main__":
+    main()
