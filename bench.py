@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- reconstructed frames/s of the cista-eiflow hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 4
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one reconstructed frame for each of the B=8 independent event sequences a GPU holds
+(BASELINE.json configs[1]: cista-eiflow, 180x240, batch 8): flow net (DCEIFlow, 6 refinement iterations)
+-> any() -> warp I / warp Z -> CISTA-LSTC, fed back recurrently exactly like test_with_flow.py:120-156.
+Inputs (synthetic event voxel grids) are resident in HBM before the timed region; weights are
+seeded random (no checkpoints exist offline).  N GPUs = N x 8 sequences (weak scaling, no data-path
+collective; an RCCL all-gather collates the reconstructed frames).
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  "roofline":     dominant kernel (fp32-MFMA implicit-GEMM conv) -- algorithmic flops / HIP-event time
+  "cpu_baseline": the CPU oracle (a port of the reference graph, eager PyTorch fp32) on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--batch", type=int, default=8, help="sequences per GPU")
+    ap.add_argument("--height", type=int, default=180)
+    ap.add_argument("--width", type=int, default=240)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=3)
+    return ap.parse_args()
+
+
+def model_args(H, W):
+    return argparse.Namespace(image_dim=[H, W], num_bins=5, warp_mode="forward", base_channels=64, depth=5, ds=8,
+                              is_bi=False)
+
+
+def cpu_baseline(B, H, W, frames):
+    """The CPU oracle (port of the reference's eager fp32 graph) on the same workload, bounded sample."""
+    import weights_util as wu
+    from oracle import cista_oracle as orc
+    from cista_flow_amd.e2v.e2v_model import DCEIFlowCistaNet
+    m = DCEIFlowCistaNet(model_args(H, W))
+    wu.fill_module(m, 1234)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    # the GPU box's CPU share for one GPU is 16 cores; torch's default (all 128 logical CPUs) oversubscribes
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    states, prev = None, torch.zeros(B, 1, H, W)
+    times = []
+    with torch.no_grad():
+        for t in range(frames + 1):
+            ev = wu.synth_events(B, 5, H, W, 1234 + t)
+            t0 = time.perf_counter()
+            I, _, states = orc.eiflow_step(sd, {"event_voxel": ev, "rec_img0": prev}, states)
+            times.append(time.perf_counter() - t0)
+            prev = I
+    timed = times[1:]
+    return {"value": round(B * len(timed) / sum(timed), 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d frames of the same B=%d %dx%d cista-eiflow workload after 1 warm-up frame "
+                      "(oracle/cista_oracle.py, eager PyTorch fp32, %d threads)" % (len(timed), B, H, W, cores)}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import weights_util as wu
+    from cista_flow_amd.e2v.e2v_model import DCEIFlowCistaNet
+    B, H, W = a.batch, a.height, a.width
+    model = DCEIFlowCistaNet(model_args(H, W)).eval()
+    wu.fill_module(model, 1234)
+    model = model.to(dev)
+    model.event_flownet.return_flow_preds = True      # like the reference: every iteration's up-flow is produced
+    R = 8
+    evs = [wu.synth_events(B, 5, H, W, 1234 + 100 * rank + i).to(dev) for i in range(R)]
+    gathered = torch.empty((world * B, 1, H, W), device=dev) if world > 1 else None
+    side = torch.cuda.Stream(device=dev) if world > 1 else None
+
+    state = {"prev": torch.zeros(B, 1, H, W, device=dev), "states": None, "i": 0}
+
+    def step():
+        ev = evs[state["i"] % R]
+        I, bf, st = model({"event_voxel": ev, "rec_img0": state["prev"]}, state["states"], {})
+        state["prev"], state["states"] = I, st
+        state["i"] += 1
+        if world > 1:
+            # collate the reconstructed frames of all ranks (RCCL all-gather over xGMI) off the critical path
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                dist.all_gather_into_tensor(gathered, I)
+        return I
+
+    with torch.no_grad():
+        for _ in range(max(a.warmup, 0)):
+            step()
+        if world > 1:
+            torch.cuda.current_stream().wait_stream(side)
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        if world > 1:
+            torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    assert torch.isfinite(state["prev"]).all(), "non-finite reconstruction"
+
+    roofline = None
+    if not a.no_roofline and rank == 0:
+        h = model._be().get(B, dev)
+        h.profile_enable(True)
+        nprof = min(a.steps, 10)
+        with torch.no_grad():
+            for _ in range(nprof):
+                step()
+            if world > 1:
+                torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        recs = h.profile_read()
+        h.profile_enable(False)
+        tiles = [r for r in recs[1:] if r["count"] > 0]
+        dom = max(tiles, key=lambda r: r["ms"])
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom["name"])
+            except Exception:
+                traffic = None
+        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        roofline = {
+            "bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "launches_per_step": dom["count"] / nprof,
+            "avg_launch_us": round(dom["ms"] * 1e3 / dom["count"], 2),
+            "flops_per_launch": dom["flops"] / dom["count"],
+            "all_conv": {"achieved": round(recs[0]["flops"] / (recs[0]["ms"] * 1e-3) / 1e12, 2),
+                         "ms_per_step": round(recs[0]["ms"] / nprof, 3), "launches_per_step": recs[0]["count"] / nprof,
+                         "gflop_per_step": round(recs[0]["flops"] / nprof / 1e9, 2)},
+            "by_kernel": {r["name"]: {"ms_per_step": round(r["ms"] / nprof, 3),
+                                      "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2),
+                                      "launches_per_step": r["count"] / nprof} for r in tiles},
+        }
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(B, H, W, a.cpu_frames)
+
+    if rank == 0:
+        value = world * B * a.steps / el
+        out = {
+            "metric": "reconstructed frames/sec at 180x240, cista-eiflow", "value": round(value, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cista-eiflow %dx%d batch=%d sequences per GPU (BASELINE configs[1]), DCEIFlow 6 iters, "
+                                   "CISTA depth 5, seeded random weights" % (H, W, B),
+                       "sequences_per_gpu": B, "height": H, "width": W, "parallelism": "dp%d (independent sequences)" % world},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

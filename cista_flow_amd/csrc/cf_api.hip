@@ -95,6 +95,18 @@ struct cf_handle {
           *motion = nullptr, *zbuf = nullptr, *rh = nullptr, *fh = nullptr;
     static constexpr int CORR_LD = 336;   // 4*81 = 324 correlation channels padded to a multiple of 16
 
+    // per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
+    struct ProfRec { int tile; double flops; hipEvent_t a, b; };
+    bool prof = false;
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> prof_pool;
+    hipEvent_t prof_event() {
+        if (!prof_pool.empty()) { hipEvent_t e = prof_pool.back(); prof_pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+
     int fail(int code, const std::string& msg) {
         err = msg;
         return code;
@@ -108,6 +120,21 @@ struct cf_handle {
             return (h)->fail(CF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e) + " @" + \
                                              std::to_string(__LINE__));                              \
     } while (0)
+
+// every convolution of the graphs goes through here (optional HIP-event bracketing)
+static hipError_t run_conv(cf_handle* h, const ConvParams& p, int batch, hipStream_t st, int tile = 0) {
+    if (!h || !h->prof) return launch_conv(p, batch, st, tile);
+    cf_handle::ProfRec r;
+    r.a = h->prof_event();
+    r.b = h->prof_event();
+    r.flops = 2.0 * (double)p.Ho * p.Wo * p.cout * (double)p.k_real * batch;
+    r.tile = 0;
+    (void)hipEventRecord(r.a, st);
+    hipError_t e = launch_conv(p, batch, st, tile, &r.tile);
+    (void)hipEventRecord(r.b, st);
+    h->prof_recs.push_back(r);
+    return e;
+}
 
 // ---------------------------------------------------------------------------------------------
 // workspace layout
@@ -204,6 +231,7 @@ ConvParams nhwc_conv(const PackedConv& pc, std::initializer_list<Seg> segs, int 
     p.a_mode = A_NHWC;
     p.w = pc.w; p.w_bs = 0; p.w_rows = pc.rows; p.Ktot = pc.Ktot; p.cin_pad = pc.cin_pad; p.bias = pc.bias;
     p.out = out; p.out_ld = out_ld; p.out_bs = out_bs; p.cout = pc.cout; p.epi = epi;
+    p.k_real = pc.cin * pc.KH * pc.KW;
     return p;
 }
 
@@ -219,6 +247,7 @@ ConvParams gather_conv(const PackedConv& pc, const float* in, int Cin, int Hsrc,
     p.g_cin = Cin; p.g_offy = offy; p.g_offx = offx; p.g_scale = scale; p.g_shift = shift; p.g_subgrid = subgrid;
     p.w = pc.w; p.w_rows = pc.rows; p.Ktot = pc.Ktot; p.cin_pad = 0; p.bias = pc.bias;
     p.out = out; p.out_ld = out_ld; p.out_bs = out_bs; p.cout = pc.cout; p.epi = epi;
+    p.k_real = pc.cin * pc.KH * pc.KW;
     return p;
 }
 
@@ -465,11 +494,43 @@ extern "C" void cf_destroy(cf_handle* h) {
     (void)hipSetDevice(h->cfg.device);
     for (void* p : h->owned) (void)hipFree(p);
     if (h->arena_mem) (void)hipFree(h->arena_mem);
+    for (auto& r : h->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : h->prof_pool) (void)hipEventDestroy(e);
     delete h;
 }
 
 extern "C" const char* cf_last_error(const cf_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 extern "C" size_t cf_workspace_bytes(const cf_handle* h) { return h ? h->arena.cap : 0; }
+
+// ---------------------------------------------------------------------------------------------
+// profiling (bench.py): HIP events around every conv launch, on the stream the launch uses
+// ---------------------------------------------------------------------------------------------
+extern "C" int cf_profile_enable(cf_handle* h, int on) {
+    if (!h) return CF_ERR_ARG;
+    h->prof = on != 0;
+    return CF_OK;
+}
+
+// Synchronises the recorded events, then for tile kind t = 1..6 (conv_igemm.hip) accumulates
+// ms[t] (sum of launch durations), flops[t] (sum of algorithmic flops), count[t]; index 0 = totals.
+extern "C" int cf_profile_read(cf_handle* h, double* ms, double* flops, long long* count, int n) {
+    if (!h || !ms || !flops || !count || n < 7) return CF_ERR_ARG;
+    for (int i = 0; i < n; ++i) { ms[i] = 0; flops[i] = 0; count[i] = 0; }
+    for (auto& r : h->prof_recs) {
+        float t = 0.f;
+        if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&t, r.a, r.b) != hipSuccess)
+            return h->fail(CF_ERR_HIP, "cf_profile_read: event query failed");
+        const int k = (r.tile >= 1 && r.tile <= 6) ? r.tile : 0;
+        if (k) { ms[k] += t; flops[k] += r.flops; count[k] += 1; }
+        ms[0] += t; flops[0] += r.flops; count[0] += 1;
+        h->prof_pool.push_back(r.a);
+        h->prof_pool.push_back(r.b);
+    }
+    h->prof_recs.clear();
+    return CF_OK;
+}
+
+extern "C" const char* cf_conv_tile_name(int tile) { return conv_tile_name(tile); }
 
 // ---------------------------------------------------------------------------------------------
 // a4 warp
@@ -501,22 +562,22 @@ static int cista_forward(cf_handle* h, const float* ev, const float* img, const 
     {
         ConvParams p = gather_conv(h->conv["cista.We"], ev, bins, H, W, 0, 0, 1.f, 0.f, 0, H, W, 1, 1, 1, 1, h->xcat, bc,
                                    HW * bc, EPI_NONE);
-        CF_HIP(h, launch_conv(p, B, st));
+        CF_HIP(h, run_conv(h, p, B, st));
         ConvParams q = gather_conv(h->conv["cista.Wi"], img, 1, H, W, 0, 0, 1.f, 0.f, 0, H, W, 1, 1, 1, 1,
                                    h->xcat + bc / 2, bc, HW * bc, EPI_NONE);
-        CF_HIP(h, launch_conv(q, B, st));
+        CF_HIP(h, run_conv(h, q, B, st));
         ConvParams r = nhwc_conv(h->conv["cista.W0"], {{h->xcat, bc, bc, HW * bc}}, H, W, hh, ww, 2, 1, 1, 1, h->x1, bc,
                                  hw * bc, EPI_NONE);
-        CF_HIP(h, launch_conv(r, B, st));
+        CF_HIP(h, run_conv(h, r, B, st));
     }
     // ConvLSTC  base_layers.py:52-71
     {
         ConvParams g = nhwc_conv(h->conv["cista.gates"], {{h->x1, bc, bc, hw * bc}, {z_prev, c2, c2, hw * c2}}, hh, ww, hh,
                                  ww, 1, 1, 1, 1, h->ifbuf, 2 * c2, hw * 2 * c2, EPI_SIGMOID);
-        CF_HIP(h, launch_conv(g, B, st));
+        CF_HIP(h, run_conv(h, g, B, st));
         ConvParams p0 = nhwc_conv(h->conv["cista.P0"], {{h->x1, bc, bc, hw * bc}}, hh, ww, hh, ww, 1, 1, 1, 1, h->z0, c2,
                                   hw * c2, EPI_NONE);
-        CF_HIP(h, launch_conv(p0, B, st));
+        CF_HIP(h, run_conv(h, p0, B, st));
         ConvParams og = nhwc_conv(h->conv["cista.out_gates"], {{h->z0, c2, c2, hw * c2}, {z_prev, c2, c2, hw * c2}}, hh, ww,
                                   hh, ww, 1, 1, 1, 1, z_out, c2, hw * c2, EPI_LSTC);
         og.split = c2;
@@ -524,29 +585,29 @@ static int cista_forward(cf_handle* h, const float* ev, const float* img, const 
         set_aux1(og, h->z0, c2, hw * c2);
         set_aux2(og, c_prev, c2, hw * c2);
         set_out2(og, c_out, c2, hw * c2);
-        CF_HIP(h, launch_conv(og, B, st));
+        CF_HIP(h, run_conv(h, og, B, st));
     }
     // unrolled ISTA, shared D / P / Lambda   e2v_model.py:81-87
     for (int i = 0; i < h->cfg.depth; ++i) {
         ConvParams d = nhwc_conv(h->conv["cista.D"], {{z_out, c2, c2, hw * c2}}, hh, ww, hh, ww, 1, 1, 1, 1, h->xt, bc,
                                  hw * bc, EPI_SUB_FROM_AUX);
         set_aux0(d, h->x1, bc, hw * bc);
-        CF_HIP(h, launch_conv(d, B, st));
+        CF_HIP(h, run_conv(h, d, B, st));
         ConvParams p = nhwc_conv(h->conv["cista.P"], {{h->xt, bc, bc, hw * bc}}, hh, ww, hh, ww, 1, 1, 1, 1, z_out, c2,
                                  hw * c2, EPI_ADD_AUX_SHRINK);
         set_aux0(p, z_out, c2, hw * c2);
         p.lam = h->lambda;
-        CF_HIP(h, launch_conv(p, B, st));
+        CF_HIP(h, run_conv(h, p, B, st));
     }
     // Dg: conv+relu, ConvLSTM   base_layers.py:223-227, 90-132
     {
         ConvParams d = nhwc_conv(h->conv["cista.Dg"], {{z_out, c2, c2, hw * c2}}, hh, ww, hh, ww, 1, 1, 1, 1, h->recx, bc,
                                  hw * bc, EPI_RELU);
-        CF_HIP(h, launch_conv(d, B, st));
+        CF_HIP(h, run_conv(h, d, B, st));
         ConvParams g = nhwc_conv(h->conv["cista.Gates"], {{h->recx, bc, bc, hw * bc}, {h_prev, bc, bc, hw * bc}}, hh, ww,
                                  hh, ww, 1, 1, 1, 1, h->gbuf, 4 * bc, hw * 4 * bc, EPI_LSTM_ACT);
         g.split = 3 * bc;
-        CF_HIP(h, launch_conv(g, B, st));
+        CF_HIP(h, run_conv(h, g, B, st));
         CF_HIP(h, launch_lstm_cell(h->gbuf, 4 * bc, hw * 4 * bc, cc_prev, bc, hw * bc, h_out, bc, hw * bc, cc_out, bc,
                                    hw * bc, B, (int)hw, bc, st));
     }
@@ -557,10 +618,10 @@ static int cista_forward(cf_handle* h, const float* ev, const float* img, const 
         u.a_mode = A_UPS2X;
         u.Hsrc = hh;
         u.Wsrc = ww;
-        CF_HIP(h, launch_conv(u, B, st));
+        CF_HIP(h, run_conv(h, u, B, st));
         ConvParams f = nhwc_conv(h->conv["cista.final"], {{h->up, bc, bc, HW * bc}}, H, W, H, W, 1, 1, 1, 1, I_out, 1, HW,
                                  EPI_SIGMOID);
-        CF_HIP(h, launch_conv(f, B, st));
+        CF_HIP(h, run_conv(h, f, B, st));
     }
     return CF_OK;
 }
@@ -592,7 +653,7 @@ static int encoder_forward(cf_handle* h, const std::string& pre, bool bn, const 
     {
         ConvParams p = gather_conv(K("conv1"), in, Cin, h->H, h->W, h->padH, h->padW, scale, shift, 0, Hc, Wc, 2, 3, 3, 0,
                                    bn ? A : Bf, 64, (long)Hc * Wc * 64, bn ? EPI_RELU : EPI_NONE);
-        CF_HIP(h, launch_conv(p, B, st));
+        CF_HIP(h, run_conv(h, p, B, st));
         if (!bn) {
             CF_HIP(h, launch_inorm_stats(Bf, 64, (long)Hc * Wc * 64, B, Hc * Wc, 64, eps, h->encPartial, h->encStats, st));
             CF_HIP(h, launch_inorm_apply(Bf, 64, (long)Hc * Wc * 64, h->encStats, nullptr, 0, 0, nullptr, A, 64,
@@ -612,26 +673,26 @@ static int encoder_forward(cf_handle* h, const std::string& pre, bool bn, const 
             if (bn) {
                 // y = relu(bn1(conv1(x))) ; y = relu(bn2(conv2(y))) ; out = relu(x' + y)
                 ConvParams c1 = nhwc_conv(K(b + ".conv1"), {{A, Cx, Cx, ibs}}, Hc, Wc, Ho, Wo, stride, 1, 1, 0, Bf, Cd, obs, EPI_RELU);
-                CF_HIP(h, launch_conv(c1, B, st));
+                CF_HIP(h, run_conv(h, c1, B, st));
                 const float* res = A;
                 int res_ld = Cx;
                 long res_bs = ibs;
                 if (stride != 1) {
                     ConvParams ds = nhwc_conv(K(b + ".downsample.0"), {{A, Cx, Cx, ibs}}, Hc, Wc, Ho, Wo, stride, 0, 0, 0, Cf, Cd, obs, EPI_NONE);
-                    CF_HIP(h, launch_conv(ds, B, st));
+                    CF_HIP(h, run_conv(h, ds, B, st));
                     res = Cf; res_ld = Cd; res_bs = obs;
                 }
                 ConvParams c2 = nhwc_conv(K(b + ".conv2"), {{Bf, Cd, Cd, obs}}, Ho, Wo, Ho, Wo, 1, 1, 1, 0, Df, Cd, obs, EPI_RELU_ADD_AUX_RELU);
                 set_aux0(c2, res, res_ld, res_bs);
-                CF_HIP(h, launch_conv(c2, B, st));
+                CF_HIP(h, run_conv(h, c2, B, st));
                 std::swap(A, Df);
             } else {
                 ConvParams c1 = nhwc_conv(K(b + ".conv1"), {{A, Cx, Cx, ibs}}, Hc, Wc, Ho, Wo, stride, 1, 1, 0, Bf, Cd, obs, EPI_NONE);
-                CF_HIP(h, launch_conv(c1, B, st));
+                CF_HIP(h, run_conv(h, c1, B, st));
                 CF_HIP(h, launch_inorm_stats(Bf, Cd, obs, B, Ho * Wo, Cd, eps, h->encPartial, h->encStats, st));
                 CF_HIP(h, launch_inorm_apply(Bf, Cd, obs, h->encStats, nullptr, 0, 0, nullptr, Cf, Cd, obs, B, Ho * Wo, Cd, st));
                 ConvParams c2 = nhwc_conv(K(b + ".conv2"), {{Cf, Cd, Cd, obs}}, Ho, Wo, Ho, Wo, 1, 1, 1, 0, Bf, Cd, obs, EPI_NONE);
-                CF_HIP(h, launch_conv(c2, B, st));
+                CF_HIP(h, run_conv(h, c2, B, st));
                 CF_HIP(h, launch_inorm_stats(Bf, Cd, obs, B, Ho * Wo, Cd, eps, h->encPartial, h->encStats, st));
                 const float* res = A;
                 int res_ld = Cx;
@@ -639,7 +700,7 @@ static int encoder_forward(cf_handle* h, const std::string& pre, bool bn, const 
                 const float* res_stats = nullptr;
                 if (stride != 1) {
                     ConvParams ds = nhwc_conv(K(b + ".downsample.0"), {{A, Cx, Cx, ibs}}, Hc, Wc, Ho, Wo, stride, 0, 0, 0, Cf, Cd, obs, EPI_NONE);
-                    CF_HIP(h, launch_conv(ds, B, st));
+                    CF_HIP(h, run_conv(h, ds, B, st));
                     CF_HIP(h, launch_inorm_stats(Cf, Cd, obs, B, Ho * Wo, Cd, eps, h->encPartial, h->encStats2, st));
                     res = Cf; res_ld = Cd; res_bs = obs; res_stats = h->encStats2;
                 }
@@ -653,13 +714,13 @@ static int encoder_forward(cf_handle* h, const std::string& pre, bool bn, const 
     const long N = (long)Hc * Wc;
     if (!out2) {
         ConvParams c = nhwc_conv(K("conv2"), {{A, Cx, Cx, N * Cx}}, Hc, Wc, Hc, Wc, 1, 0, 0, 0, out, 256, N * 256, EPI_NONE);
-        CF_HIP(h, launch_conv(c, B, st));
+        CF_HIP(h, run_conv(h, c, B, st));
     } else {
         // net, inp = split(cnet, [128,128]); tanh / relu   DCEIFlow.py:193-196
         ConvParams c = nhwc_conv(K("conv2"), {{A, Cx, Cx, N * Cx}}, Hc, Wc, Hc, Wc, 1, 0, 0, 0, out, 128, N * 128, EPI_TANH_RELU_SPLIT);
         c.split = 128;
         set_out2(c, out2, 128, N * 128);
-        CF_HIP(h, launch_conv(c, B, st));
+        CF_HIP(h, run_conv(h, c, B, st));
     }
     return CF_OK;
 }
@@ -679,12 +740,12 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
     // EIFusion  DCEIFlow.py:39-44
     {
         ConvParams a = nhwc_conv(h->conv["fusion.conv1"], {{h->fmap1, 256, 256, N * 256}}, h8, w8, h8, w8, 1, 0, 0, 0, h->fcat, 384, N * 384, EPI_RELU);
-        CF_HIP(h, launch_conv(a, B, st));
+        CF_HIP(h, run_conv(h, a, B, st));
         ConvParams b = nhwc_conv(h->conv["fusion.conv2"], {{h->emap, 256, 256, N * 256}}, h8, w8, h8, w8, 1, 0, 0, 0, h->fcat + 192, 384, N * 384, EPI_RELU);
-        CF_HIP(h, launch_conv(b, B, st));
+        CF_HIP(h, run_conv(h, b, B, st));
         ConvParams o = nhwc_conv(h->conv["fusion.convo"], {{h->fcat, 384, 384, N * 384}}, h8, w8, h8, w8, 1, 1, 1, 0, h->pfmap2, 256, N * 256, EPI_RELU_ADD_AUX);
         set_aux0(o, h->fmap1, 256, N * 256);
-        CF_HIP(h, launch_conv(o, B, st));
+        CF_HIP(h, run_conv(h, o, B, st));
     }
     // all-pairs correlation + pyramid   raft_corr.py:22-30,56-65
     {
@@ -695,16 +756,17 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
         p.w = h->pfmap2; p.w_bs = N * 256; p.w_rows = (int)N; p.Ktot = 256; p.cin_pad = 256;
         p.out = h->corr[0]; p.out_ld = (int)N; p.out_bs = N * N; p.cout = (int)N; p.epi = EPI_SCALE;
         p.scale = 1.0f / sqrtf(256.f);
-        CF_HIP(h, launch_conv(p, B, st));
+        p.k_real = 256;
+        CF_HIP(h, run_conv(h, p, B, st));
         for (int l = 1; l < 4; ++l)
             CF_HIP(h, launch_corr_pool(h->corr[l - 1], h->corr[l], (long)B * N, h->clh[l - 1], h->clw[l - 1], st));
     }
     // emap branch of the motion encoder is iteration-invariant (with_event_updater.py:105-106)
     {
         ConvParams a = nhwc_conv(h->conv["conve1"], {{h->emap, 256, 256, N * 256}}, h8, w8, h8, w8, 1, 0, 0, 0, h->e1buf, 128, N * 128, EPI_RELU);
-        CF_HIP(h, launch_conv(a, B, st));
+        CF_HIP(h, run_conv(h, a, B, st));
         ConvParams b = nhwc_conv(h->conv["conve2"], {{h->e1buf, 128, 128, N * 128}}, h8, w8, h8, w8, 1, 1, 1, 0, h->mcat + 192, 320, N * 320, EPI_RELU);
-        CF_HIP(h, launch_conv(b, B, st));
+        CF_HIP(h, run_conv(h, b, B, st));
     }
     CF_HIP(h, launch_coords_init(h->coords1, flow_init, B, h8, w8, st));
     if (flag) CF_HIP(h, hipMemsetAsync(flag, 0, sizeof(int), st));
@@ -719,15 +781,15 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
         CF_HIP(h, launch_corr_lookup(lp, st));
         // BasicMotionEncoder  with_event_updater.py:102-112
         ConvParams c1 = nhwc_conv(h->conv["convc1"], {{h->corrfeat, cf_handle::CORR_LD, cf_handle::CORR_LD, N * cf_handle::CORR_LD}}, h8, w8, h8, w8, 1, 0, 0, 0, h->c1buf, 256, N * 256, EPI_RELU);
-        CF_HIP(h, launch_conv(c1, B, st));
+        CF_HIP(h, run_conv(h, c1, B, st));
         ConvParams c2 = nhwc_conv(h->conv["convc2"], {{h->c1buf, 256, 256, N * 256}}, h8, w8, h8, w8, 1, 1, 1, 0, h->mcat, 320, N * 320, EPI_RELU);
-        CF_HIP(h, launch_conv(c2, B, st));
+        CF_HIP(h, run_conv(h, c2, B, st));
         ConvParams f1 = gather_conv(h->conv["convf1"], h->coords1, 2, h8, w8, 0, 0, 1.f, 0.f, 1, h8, w8, 1, 3, 3, 0, h->f1buf, 128, N * 128, EPI_RELU);
-        CF_HIP(h, launch_conv(f1, B, st));
+        CF_HIP(h, run_conv(h, f1, B, st));
         ConvParams f2 = nhwc_conv(h->conv["convf2"], {{h->f1buf, 128, 128, N * 128}}, h8, w8, h8, w8, 1, 1, 1, 0, h->mcat + 256, 320, N * 320, EPI_RELU);
-        CF_HIP(h, launch_conv(f2, B, st));
+        CF_HIP(h, run_conv(h, f2, B, st));
         ConvParams mc = nhwc_conv(h->conv["menc.conv"], {{h->mcat, 320, 320, N * 320}}, h8, w8, h8, w8, 1, 1, 1, 0, h->motion, 128, N * 128, EPI_RELU);
-        CF_HIP(h, launch_conv(mc, B, st));
+        CF_HIP(h, run_conv(h, mc, B, st));
         // SepConvGRU  with_event_updater.py:52-67 ; hx = cat(h, inp, motion)
         for (int pass = 0; pass < 2; ++pass) {
             const PackedConv& zr = h->conv[pass == 0 ? "gru.zr1" : "gru.zr2"];
@@ -737,19 +799,19 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
             a.split = 128;
             set_aux0(a, h->net, 128, N * 128);
             set_out2(a, h->rh, 128, N * 128);
-            CF_HIP(h, launch_conv(a, B, st));
+            CF_HIP(h, run_conv(h, a, B, st));
             ConvParams q = nhwc_conv(qq, {{h->rh, 128, 128, N * 128}, {h->inp, 128, 128, N * 128}, {h->motion, 128, 128, N * 128}}, h8, w8, h8, w8, 1, pT, pL, 0, h->net, 128, N * 128, EPI_GRU_Q);
             set_aux0(q, h->zbuf, 128, N * 128);
             set_aux1(q, h->net, 128, N * 128);
-            CF_HIP(h, launch_conv(q, B, st));
+            CF_HIP(h, run_conv(h, q, B, st));
         }
         // FlowHead + coords1 += delta_flow   with_event_updater.py:13-14, DCEIFlow.py:218
         ConvParams h1 = nhwc_conv(h->conv["fh.conv1"], {{h->net, 128, 128, N * 128}}, h8, w8, h8, w8, 1, 1, 1, 0, h->fh, 256, N * 256, EPI_RELU);
-        CF_HIP(h, launch_conv(h1, B, st));
+        CF_HIP(h, run_conv(h, h1, B, st));
         ConvParams h2 = nhwc_conv(h->conv["fh.conv2"], {{h->fh, 256, 256, N * 256}}, h8, w8, h8, w8, 1, 1, 1, 0, h->coords1, 1, 2 * N, EPI_ADD_AUX);
         h2.out_cs = (int)N;
         set_aux0(h2, h->coords1, 1, 2 * N, (int)N);
-        CF_HIP(h, launch_conv(h2, B, st));
+        CF_HIP(h, run_conv(h, h2, B, st));
         // upflow8 + unpad   DCEIFlow.py:222-227
         const bool last = it == iters - 1;
         float* up = flow_preds ? flow_preds + (long)it * B * 2 * h->Hp * h->Wp : nullptr;

@@ -78,10 +78,12 @@ struct ConvParams {
     const float* aux2; int aux2_ld; long aux2_bs;
     const float* aux3; int aux3_ld; long aux3_bs;
     const float* lam;   // [cout] soft-threshold
+    int  k_real;        // un-padded K (taps * Cin): algorithmic-flop bookkeeping only
 };
 
-// tile: 0 auto, else explicit (see conv_igemm.hip)
-hipError_t launch_conv(const ConvParams& p, int batch, hipStream_t s, int tile = 0);
+// tile: 0 auto, else explicit (see conv_igemm.hip); tile_used (nullable) returns the choice
+hipError_t launch_conv(const ConvParams& p, int batch, hipStream_t s, int tile = 0, int* tile_used = nullptr);
+const char* conv_tile_name(int tile);
 
 // ---------------------------------------------------------------------------
 // Weight packing (device side, runs once per load_state_dict)

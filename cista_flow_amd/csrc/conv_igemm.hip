@@ -427,7 +427,19 @@ static hipError_t launch_t(const ConvParams& p, int batch, hipStream_t s) {
 }
 
 // tile ids: 1 = 128x128, 2 = 128x64, 3 = 128x96, 4 = 64x64, 5 = 64x128, 6 = 128x32
-hipError_t launch_conv(const ConvParams& p, int batch, hipStream_t s, int tile) {
+const char* conv_tile_name(int tile) {
+    switch (tile) {
+        case 1: return "conv_igemm_kernel<128,128,2,2>";
+        case 2: return "conv_igemm_kernel<128,64,2,2>";
+        case 3: return "conv_igemm_kernel<128,96,4,1>";
+        case 4: return "conv_igemm_kernel<64,64,2,2>";
+        case 5: return "conv_igemm_kernel<64,128,2,2>";
+        case 6: return "conv_igemm_kernel<128,32,4,1>";
+        default: return "?";
+    }
+}
+
+hipError_t launch_conv(const ConvParams& p, int batch, hipStream_t s, int tile, int* tile_used) {
     // ---- host-side shape checks: a bad descriptor must never reach the GPU ----
     if (p.Ktot <= 0 || (p.Ktot % KC) != 0 || p.cout <= 0 || batch <= 0 || p.Ho <= 0 || p.Wo <= 0)
         return hipErrorInvalidValue;
@@ -471,6 +483,7 @@ hipError_t launch_conv(const ConvParams& p, int batch, hipStream_t s, int tile) 
         else if (bn == 64) tile = (wg128 >= 512) ? 2 : 4;
         else tile = (wg128 >= 512) ? 1 : ((long)((M + 63) / 64) * ((p.cout + 127) / 128) * batch >= 512 ? 5 : 4);
     }
+    if (tile_used) *tile_used = tile;
     switch (tile) {
         case 1: return launch_t<128, 128, 2, 2>(p, batch, s);
         case 2: return launch_t<128, 64, 2, 2>(p, batch, s);

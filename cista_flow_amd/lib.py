@@ -17,7 +17,7 @@ SYMBOLS = [
     "cf_create", "cf_destroy", "cf_last_error", "cf_workspace_bytes", "cf_load_weights",
     "cf_finalize_weights", "cf_warp", "cf_cista_forward", "cf_flow_forward", "cf_step",
     "cf_op_conv2d", "cf_op_instance_norm_relu", "cf_op_corr_lookup", "cf_op_nchw_to_nhwc",
-    "cf_op_nhwc_to_nchw",
+    "cf_op_nhwc_to_nchw", "cf_profile_enable", "cf_profile_read", "cf_conv_tile_name",
 ]
 
 
@@ -41,6 +41,9 @@ def load():
         raise RuntimeError(
             "libcistaflow.so not found at %s -- build it first (python -c 'import __graft_entry__ as g; g.build()'). "
             "There is no CPU fallback for the CISTA-Flow hot path." % LIB_PATH)
+    # torch first: PyTorch-ROCm bundles its own libamdhip64.so.7; loading it before ours makes both sides of
+    # the boundary share ONE HIP runtime (two runtimes in a process cannot see each other's device pointers)
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     fp, vp, i = C.c_void_p, C.c_void_p, C.c_int
     lib.cf_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(cf_config)]
@@ -73,6 +76,12 @@ def load():
     lib.cf_op_nchw_to_nhwc.restype = i
     lib.cf_op_nhwc_to_nchw.argtypes = [fp, fp, i, i, i, i, vp]
     lib.cf_op_nhwc_to_nchw.restype = i
+    lib.cf_profile_enable.argtypes = [vp, i]
+    lib.cf_profile_enable.restype = i
+    lib.cf_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong), i]
+    lib.cf_profile_read.restype = i
+    lib.cf_conv_tile_name.argtypes = [i]
+    lib.cf_conv_tile_name.restype = C.c_char_p
     _lib = lib
     return lib
 
@@ -133,6 +142,20 @@ class Handle:
             self.check(self.lib.cf_load_weights(self.h, k.encode(), ptr(t), shp, t.dim()), "cf_load_weights(%s)" % k)
         self.check(self.lib.cf_finalize_weights(self.h, current_stream_ptr()), "cf_finalize_weights")
         del keep
+
+    def profile_enable(self, on=True):
+        self.check(self.lib.cf_profile_enable(self.h, 1 if on else 0), "cf_profile_enable")
+
+    def profile_read(self):
+        """-> list of dicts per conv tile kind: name, ms, flops, count (index 0 = all conv launches)."""
+        n = 7
+        ms, fl, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_longlong * n)()
+        self.check(self.lib.cf_profile_read(self.h, ms, fl, cnt, n), "cf_profile_read")
+        out = []
+        for t in range(n):
+            name = "conv_igemm_kernel<*>" if t == 0 else self.lib.cf_conv_tile_name(t).decode()
+            out.append(dict(name=name, ms=ms[t], flops=fl[t], count=int(cnt[t])))
+        return out
 
     @property
     def workspace_bytes(self):

@@ -97,6 +97,14 @@ int cf_step(cf_handle* h, const float* in0, const float* in1, const float* rec_i
             const float* cc_prev, float* I_out, float* flow_final, float* flow_low, float* flow_preds,
             float* z_warped_out, float* c_out, float* z_out, float* h_out, float* cc_out, void* stream);
 
+/* measurement: when enabled, every convolution launch of the fused paths is bracketed by HIP events on
+ * the launch stream.  cf_profile_read synchronises them and returns, for conv tile kind t = 1..6
+ * (index 0 = all), the summed launch duration in ms, the summed algorithmic flops (2*M*N*K with the
+ * un-padded K) and the launch count, then clears the records.  cf_conv_tile_name(t) = kernel symbol. */
+int cf_profile_enable(cf_handle* h, int on);
+int cf_profile_read(cf_handle* h, double* ms, double* flops, long long* count, int n);
+const char* cf_conv_tile_name(int tile);
+
 /* single-operator entry points (used by the parity tests; same kernels as the fused paths) ------ */
 /* conv2d on NHWC input (a_mode 0), fused x2-upsample input (a_mode 1) or planar NCHW small-Cin input
  * (a_mode 2); weight OIHW; out NHWC [B][Ho][Wo][Cout].  epi: 0 none 1 relu 2 sigmoid 3 tanh. */
