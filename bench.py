@@ -156,6 +156,9 @@ def main():
         torch.cuda.synchronize()
         recs = h.profile_read()
         h.profile_enable(False)
+        if os.environ.get("CF_LAYER_REPORT"):
+            with open(os.environ["CF_LAYER_REPORT"], "w") as f:
+                f.write("# per-layer conv timing over %d steps (HIP events)\n" % nprof + h.profile_report())
         tiles = [r for r in recs[1:] if r["count"] > 0]
         dom = max(tiles, key=lambda r: r["ms"])
         traffic = None

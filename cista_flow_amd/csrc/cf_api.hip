@@ -42,6 +42,7 @@ struct PackedConv {
     float* bias = nullptr;
     int cout = 0, cin = 0, cin_pad = 0, KH = 0, KW = 0, Ktot = 0, rows = 0;
     bool gather = false;
+    std::string name;
 };
 
 struct Arena {
@@ -96,7 +97,9 @@ struct cf_handle {
     static constexpr int CORR_LD = 336;   // 4*81 = 324 correlation channels padded to a multiple of 16
 
     // per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
-    struct ProfRec { int tile; double flops; hipEvent_t a, b; };
+    struct ProfRec { int tile; double flops; hipEvent_t a, b; const char* tag; };
+    const char* tag = "";
+    std::string prof_report;
     bool prof = false;
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> prof_pool;
@@ -122,6 +125,7 @@ struct cf_handle {
     } while (0)
 
 // every convolution of the graphs goes through here (optional HIP-event bracketing)
+#define TAG(h, t) ((h)->tag = (t))
 static hipError_t run_conv(cf_handle* h, const ConvParams& p, int batch, hipStream_t st, int tile = 0) {
     if (!h || !h->prof) return launch_conv(p, batch, st, tile);
     cf_handle::ProfRec r;
@@ -129,6 +133,7 @@ static hipError_t run_conv(cf_handle* h, const ConvParams& p, int batch, hipStre
     r.b = h->prof_event();
     r.flops = 2.0 * (double)p.Ho * p.Wo * p.cout * (double)p.k_real * batch;
     r.tile = 0;
+    r.tag = p.tag ? p.tag : h->tag;
     (void)hipEventRecord(r.a, st);
     hipError_t e = launch_conv(p, batch, st, tile, &r.tile);
     (void)hipEventRecord(r.b, st);
@@ -232,6 +237,7 @@ ConvParams nhwc_conv(const PackedConv& pc, std::initializer_list<Seg> segs, int 
     p.w = pc.w; p.w_bs = 0; p.w_rows = pc.rows; p.Ktot = pc.Ktot; p.cin_pad = pc.cin_pad; p.bias = pc.bias;
     p.out = out; p.out_ld = out_ld; p.out_bs = out_bs; p.cout = pc.cout; p.epi = epi;
     p.k_real = pc.cin * pc.KH * pc.KW;
+    p.tag = pc.name.c_str();
     return p;
 }
 
@@ -248,6 +254,7 @@ ConvParams gather_conv(const PackedConv& pc, const float* in, int Cin, int Hsrc,
     p.w = pc.w; p.w_rows = pc.rows; p.Ktot = pc.Ktot; p.cin_pad = 0; p.bias = pc.bias;
     p.out = out; p.out_ld = out_ld; p.out_bs = out_bs; p.cout = pc.cout; p.epi = epi;
     p.k_real = pc.cin * pc.KH * pc.KW;
+    p.tag = pc.name.c_str();
     return p;
 }
 
@@ -276,6 +283,7 @@ static int pack_conv(cf_handle* h, const std::string& key, const std::string& pr
     const int Cout = (int)wt->shape[0], Cin = (int)wt->shape[1], KH = (int)wt->shape[2], KW = (int)wt->shape[3];
     if (bs && (bs->shape.size() != 1 || bs->shape[0] != Cout)) return h->fail(CF_ERR_WEIGHT, "bad bias shape: " + prefix);
     PackedConv& pc = h->conv[key];
+    pc.name = key;
     if (!pc.w) {
         pc.cin = Cin; pc.KH = KH; pc.KW = KW; pc.gather = gather;
         pc.cin_pad = gather ? 0 : round_up(Cin, 16);
@@ -516,6 +524,8 @@ extern "C" int cf_profile_enable(cf_handle* h, int on) {
 extern "C" int cf_profile_read(cf_handle* h, double* ms, double* flops, long long* count, int n) {
     if (!h || !ms || !flops || !count || n < 7) return CF_ERR_ARG;
     for (int i = 0; i < n; ++i) { ms[i] = 0; flops[i] = 0; count[i] = 0; }
+    struct Agg { double ms = 0, flops = 0; long cnt = 0; int tile = 0; };
+    std::map<std::string, Agg> agg;
     for (auto& r : h->prof_recs) {
         float t = 0.f;
         if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&t, r.a, r.b) != hipSuccess)
@@ -523,12 +533,25 @@ extern "C" int cf_profile_read(cf_handle* h, double* ms, double* flops, long lon
         const int k = (r.tile >= 1 && r.tile <= 6) ? r.tile : 0;
         if (k) { ms[k] += t; flops[k] += r.flops; count[k] += 1; }
         ms[0] += t; flops[0] += r.flops; count[0] += 1;
+        Agg& a = agg[r.tag ? r.tag : ""];
+        a.ms += t; a.flops += r.flops; a.cnt += 1; a.tile = r.tile;
         h->prof_pool.push_back(r.a);
         h->prof_pool.push_back(r.b);
     }
     h->prof_recs.clear();
+    h->prof_report.clear();
+    char line[256];
+    for (auto& kv : agg) {
+        snprintf(line, sizeof(line), "%-28s tile %d launches %6ld  ms %9.3f  avg_us %8.2f  TFLOP/s %7.2f\n", kv.first.c_str(),
+                 kv.second.tile, kv.second.cnt, kv.second.ms, kv.second.ms * 1e3 / kv.second.cnt,
+                 kv.second.flops / (kv.second.ms * 1e-3) / 1e12);
+        h->prof_report += line;
+    }
     return CF_OK;
 }
+
+// per-layer table of the last cf_profile_read (layer tag, tile kind, launches, time, achieved TFLOP/s)
+extern "C" const char* cf_profile_report(const cf_handle* h) { return h ? h->prof_report.c_str() : ""; }
 
 extern "C" const char* cf_conv_tile_name(int tile) { return conv_tile_name(tile); }
 
@@ -757,6 +780,7 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
         p.out = h->corr[0]; p.out_ld = (int)N; p.out_bs = N * N; p.cout = (int)N; p.epi = EPI_SCALE;
         p.scale = 1.0f / sqrtf(256.f);
         p.k_real = 256;
+        p.tag = "corr.allpairs";
         CF_HIP(h, run_conv(h, p, B, st));
         for (int l = 1; l < 4; ++l)
             CF_HIP(h, launch_corr_pool(h->corr[l - 1], h->corr[l], (long)B * N, h->clh[l - 1], h->clw[l - 1], st));

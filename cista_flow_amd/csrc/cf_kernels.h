@@ -79,6 +79,7 @@ struct ConvParams {
     const float* aux3; int aux3_ld; long aux3_bs;
     const float* lam;   // [cout] soft-threshold
     int  k_real;        // un-padded K (taps * Cin): algorithmic-flop bookkeeping only
+    const char* tag;    // layer name for the profiler (host side only)
 };
 
 // tile: 0 auto, else explicit (see conv_igemm.hip); tile_used (nullable) returns the choice

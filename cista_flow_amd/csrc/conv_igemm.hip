@@ -180,7 +180,7 @@ __device__ __forceinline__ void epilogue4(const ConvParams& p, int b, int m, int
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
     static_assert(BM % 64 == 0, "BM multiple of 64");
@@ -189,8 +189,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     constexpr int A_IT = BM / 64;
     constexpr int B_IT = (BN * 4 + 255) / 256;
     constexpr int STAGE = (BM + BN) * LDS_S;
+    constexpr int GTAB = (AMODE == A_GATHER) ? 256 : 4;
 
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+    __shared__ __attribute__((aligned(16))) int gtab[GTAB];   // A_GATHER: k -> (ky | kx<<8 | c<<16), -1 = pad
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -204,6 +206,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int q = tid & 3;
     const int rbase = tid >> 2;
 
+    // per-thread A rows (fixed for the whole K loop)
     int a_oy[A_IT], a_ox[A_IT];
     bool a_ok[A_IT];
 #pragma unroll
@@ -211,8 +214,30 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         const int m = m0 + rbase + 64 * j;
         a_ok[j] = m < M;
         const int oy = m / p.Wo;
-        a_oy[j] = oy;
-        a_ox[j] = m - oy * p.Wo;
+        a_oy[j] = oy * p.stride - p.padT;
+        a_ox[j] = (m - oy * p.Wo) * p.stride - p.padL;
+    }
+    // per-thread B rows
+    const float* b_ptr[B_IT];
+    bool b_ok[B_IT];
+    {
+        const float* wbase = p.w + (long)b * p.w_bs;
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const int row = (tid + 256 * it) >> 2;
+            b_ok[it] = row < BN && (n0 + row) < p.w_rows;
+            b_ptr[it] = wbase + (long)(b_ok[it] ? (n0 + row) : 0) * p.Ktot + q * 4;
+        }
+    }
+    if (AMODE == A_GATHER) {
+        const int ntap = p.KH * p.KW;
+        for (int k = tid; k < GTAB; k += 256) {
+            const int tap = k / p.g_cin;
+            const int c = k - tap * p.g_cin;
+            const int ky = tap / p.KW;
+            gtab[k] = (tap < ntap && k < p.Ktot) ? (ky | ((tap - ky * p.KW) << 8) | (c << 16)) : -1;
+        }
+        __syncthreads();
     }
 
     f32x16 acc[TM][TN];
@@ -224,39 +249,76 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const int nck = p.Ktot / KC;
-    const int cpt = (p.a_mode == A_GATHER) ? 1 : p.cin_pad / KC;  // chunks per tap
-    const float* wbase = p.w + (long)b * p.w_bs;
+
+    // ---- chunk iterator (wave-uniform): tap (ky,kx), channel segment, channel offset inside it ----
+    int it_ky = 0, it_kx = 0, it_seg = 0, it_cs = 0, it_k = 0;
+    const float* seg_base = p.in[0] + (long)b * p.seg_bs[0];
+    int seg_ld = p.seg_ld[0], seg_cn = p.seg_c[0];
+
+    // per-tap, per-row source pixel (element index into the NHWC plane, -1 = zero padding / out of range)
+    int a_pix[A_IT];
+    // A_UPS2X: the four bilinear taps and weights of each row
+    int u_p01[A_IT], u_p10[A_IT], u_p11[A_IT];
+    float u_ly1[A_IT], u_lx1[A_IT];
+
+    auto tap_setup = [&]() {
+#pragma unroll
+        for (int j = 0; j < A_IT; ++j) {
+            int iy = a_oy[j] + it_ky;
+            int ix = a_ox[j] + it_kx;
+            bool ok = a_ok[j];
+            if (p.pad_mode == 1) {
+                iy = reflect_idx(iy, p.Hin);
+                ix = reflect_idx(ix, p.Win);
+            } else {
+                ok = ok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+            }
+            if (AMODE == A_NHWC) {
+                a_pix[j] = ok ? iy * p.Win + ix : -1;
+            } else {   // A_UPS2X: bilinear x2 (align_corners=False) source taps of the (Hsrc,Wsrc) plane
+                float sy = ((float)iy + 0.5f) * 0.5f - 0.5f;
+                float sx = ((float)ix + 0.5f) * 0.5f - 0.5f;
+                sy = sy < 0.f ? 0.f : sy;
+                sx = sx < 0.f ? 0.f : sx;
+                const int y0 = (int)sy, x0 = (int)sx;
+                const int y1 = y0 + (y0 < p.Hsrc - 1 ? 1 : 0);
+                const int x1 = x0 + (x0 < p.Wsrc - 1 ? 1 : 0);
+                u_ly1[j] = sy - (float)y0;
+                u_lx1[j] = sx - (float)x0;
+                a_pix[j] = ok ? y0 * p.Wsrc + x0 : -1;
+                u_p01[j] = y0 * p.Wsrc + x1;
+                u_p10[j] = y1 * p.Wsrc + x0;
+                u_p11[j] = y1 * p.Wsrc + x1;
+            }
+        }
+    };
+    if (AMODE != A_GATHER) tap_setup();
 
     f32x4 a_reg[A_IT], b_reg[B_IT];
 
-    auto load_chunk = [&](int ck) {
+    auto load_chunk = [&]() {
         // ---- B: packed weights, K contiguous ----
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
-            const int slot = tid + 256 * it;
-            const int row = slot >> 2;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (row < BN && (n0 + row) < p.w_rows)
-                v = *reinterpret_cast<const f32x4*>(wbase + (long)(n0 + row) * p.Ktot + ck * KC + q * 4);
+            if (b_ok[it]) v = *reinterpret_cast<const f32x4*>(b_ptr[it] + it_k);
             b_reg[it] = v;
         }
         // ---- A ----
-        if (p.a_mode == A_GATHER) {
-            const float* src = p.in[0] + (long)b * p.seg_bs[0];
-            const int ntap = p.KH * p.KW;
+        if (AMODE == A_GATHER) {
+            const float* src = seg_base;
+            const int4 tb = *reinterpret_cast<const int4*>(&gtab[it_k + q * 4]);
+            const int te[4] = {tb.x, tb.y, tb.z, tb.w};
 #pragma unroll
             for (int j = 0; j < A_IT; ++j) {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int kk = ck * KC + q * 4 + e;
-                    const int tap = kk / p.g_cin;
-                    const int c = kk - tap * p.g_cin;
-                    const int ky = tap / p.KW;
-                    const int kx = tap - ky * p.KW;
-                    int iy = a_oy[j] * p.stride + ky - p.padT;
-                    int ix = a_ox[j] * p.stride + kx - p.padL;
-                    bool ok = a_ok[j] && tap < ntap;
+                    const int t = te[e];
+                    const int ky = t & 0xff, kx = (t >> 8) & 0xff, c = t >> 16;
+                    int iy = a_oy[j] + ky;
+                    int ix = a_ox[j] + kx;
+                    bool ok = a_ok[j] && t >= 0;
                     if (p.pad_mode == 1) {
                         iy = reflect_idx(iy, p.Hin);
                         ix = reflect_idx(ix, p.Win);
@@ -268,7 +330,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                     ok = ok && sy >= 0 && sx >= 0;
                     float x = 0.f;
                     if (ok) {
-                        x = src[((long)c * p.Hsrc + sy) * p.Wsrc + sx];
+                        x = src[(c * p.Hsrc + sy) * p.Wsrc + sx];
                         x = x * p.g_scale + p.g_shift;
                         if (p.g_subgrid) x -= (c == 0) ? (float)sx : (float)sy;
                     }
@@ -276,68 +338,52 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                 }
                 a_reg[j] = v;
             }
-        } else {
-            const int tap = ck / cpt;
-            int cc = (ck - tap * cpt) * KC;
-            const int ky = tap / p.KW;
-            const int kx = tap - ky * p.KW;
-            int s = 0;
-            while (s < p.nseg - 1 && cc >= p.seg_c[s]) {
-                cc -= p.seg_c[s];
-                ++s;
+        } else if (AMODE == A_NHWC) {
+            const float* src = seg_base + it_cs + q * 4;
+#pragma unroll
+            for (int j = 0; j < A_IT; ++j) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (a_pix[j] >= 0) v = *reinterpret_cast<const f32x4*>(src + (long)a_pix[j] * seg_ld);
+                a_reg[j] = v;
             }
-            const float* src = sel3(p.in, s) + (long)b * (s == 0 ? p.seg_bs[0] : (s == 1 ? p.seg_bs[1] : p.seg_bs[2]));
-            const int ld = s == 0 ? p.seg_ld[0] : (s == 1 ? p.seg_ld[1] : p.seg_ld[2]);
-            const int coff = cc + q * 4;
-            if (p.a_mode == A_NHWC) {
+        } else {
+            const float* src = seg_base + it_cs + q * 4;
 #pragma unroll
-                for (int j = 0; j < A_IT; ++j) {
-                    int iy = a_oy[j] * p.stride + ky - p.padT;
-                    int ix = a_ox[j] * p.stride + kx - p.padL;
-                    bool ok = a_ok[j];
-                    if (p.pad_mode == 1) {
-                        iy = reflect_idx(iy, p.Hin);
-                        ix = reflect_idx(ix, p.Win);
-                    } else {
-                        ok = ok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
-                    }
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (ok) v = *reinterpret_cast<const f32x4*>(src + ((long)iy * p.Win + ix) * ld + coff);
-                    a_reg[j] = v;
+            for (int j = 0; j < A_IT; ++j) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (a_pix[j] >= 0) {
+                    const f32x4 v00 = *reinterpret_cast<const f32x4*>(src + (long)a_pix[j] * seg_ld);
+                    const f32x4 v01 = *reinterpret_cast<const f32x4*>(src + (long)u_p01[j] * seg_ld);
+                    const f32x4 v10 = *reinterpret_cast<const f32x4*>(src + (long)u_p10[j] * seg_ld);
+                    const f32x4 v11 = *reinterpret_cast<const f32x4*>(src + (long)u_p11[j] * seg_ld);
+                    const float ly1 = u_ly1[j], lx1 = u_lx1[j];
+                    const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[e] = ly0 * (lx0 * v00[e] + lx1 * v01[e]) + ly1 * (lx0 * v10[e] + lx1 * v11[e]);
                 }
-            } else {  // A_UPS2X: bilinear x2 (align_corners=False) of the (Hsrc,Wsrc) source
-#pragma unroll
-                for (int j = 0; j < A_IT; ++j) {
-                    int uy = a_oy[j] * p.stride + ky - p.padT;
-                    int ux = a_ox[j] * p.stride + kx - p.padL;
-                    bool ok = a_ok[j];
-                    if (p.pad_mode == 1) {
-                        uy = reflect_idx(uy, p.Hin);
-                        ux = reflect_idx(ux, p.Win);
-                    } else {
-                        ok = ok && uy >= 0 && uy < p.Hin && ux >= 0 && ux < p.Win;
+                a_reg[j] = v;
+            }
+        }
+        // ---- advance the iterator to the next chunk ----
+        it_k += KC;
+        if (AMODE != A_GATHER) {
+            it_cs += KC;
+            if (it_cs >= seg_cn) {
+                it_cs = 0;
+                ++it_seg;
+                if (it_seg >= p.nseg) {
+                    it_seg = 0;
+                    ++it_kx;
+                    if (it_kx >= p.KW) {
+                        it_kx = 0;
+                        ++it_ky;
                     }
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (ok) {
-                        float sy = ((float)uy + 0.5f) * 0.5f - 0.5f;
-                        float sx = ((float)ux + 0.5f) * 0.5f - 0.5f;
-                        sy = sy < 0.f ? 0.f : sy;
-                        sx = sx < 0.f ? 0.f : sx;
-                        const int y0 = (int)sy, x0 = (int)sx;
-                        const int y1 = y0 + (y0 < p.Hsrc - 1 ? 1 : 0);
-                        const int x1 = x0 + (x0 < p.Wsrc - 1 ? 1 : 0);
-                        const float ly1 = sy - (float)y0, lx1 = sx - (float)x0;
-                        const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
-                        const f32x4 v00 = *reinterpret_cast<const f32x4*>(src + ((long)y0 * p.Wsrc + x0) * ld + coff);
-                        const f32x4 v01 = *reinterpret_cast<const f32x4*>(src + ((long)y0 * p.Wsrc + x1) * ld + coff);
-                        const f32x4 v10 = *reinterpret_cast<const f32x4*>(src + ((long)y1 * p.Wsrc + x0) * ld + coff);
-                        const f32x4 v11 = *reinterpret_cast<const f32x4*>(src + ((long)y1 * p.Wsrc + x1) * ld + coff);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            v[e] = ly0 * (lx0 * v00[e] + lx1 * v01[e]) + ly1 * (lx0 * v10[e] + lx1 * v11[e]);
-                    }
-                    a_reg[j] = v;
+                    tap_setup();
                 }
+                seg_base = sel3(p.in, it_seg) + (long)b * (it_seg == 0 ? p.seg_bs[0] : (it_seg == 1 ? p.seg_bs[1] : p.seg_bs[2]));
+                seg_ld = it_seg == 0 ? p.seg_ld[0] : (it_seg == 1 ? p.seg_ld[1] : p.seg_ld[2]);
+                seg_cn = it_seg == 0 ? p.seg_c[0] : (it_seg == 1 ? p.seg_c[1] : p.seg_c[2]);
             }
         }
     };
@@ -350,13 +396,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             *reinterpret_cast<f32x4*>(sA + (rbase + 64 * j) * LDS_S + q * 4) = a_reg[j];
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
-            const int slot = tid + 256 * it;
-            const int row = slot >> 2;
+            const int row = (tid + 256 * it) >> 2;
             if (row < BN) *reinterpret_cast<f32x4*>(sB + row * LDS_S + q * 4) = b_reg[it];
         }
     };
 
-    load_chunk(0);
+    load_chunk();
     store_chunk(0);
     __syncthreads();
 
@@ -364,7 +409,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int lh = lane >> 5;
     for (int ck = 0; ck < nck; ++ck) {
         const int buf = ck & 1;
-        if (ck + 1 < nck) load_chunk(ck + 1);
+        if (ck + 1 < nck) load_chunk();
         const float* sA = smem + buf * STAGE;
         const float* sB = sA + BM * LDS_S;
 #pragma unroll
@@ -422,7 +467,9 @@ template <int BM, int BN, int WM, int WN>
 static hipError_t launch_t(const ConvParams& p, int batch, hipStream_t s) {
     const int M = p.Ho * p.Wo;
     dim3 grid((M + BM - 1) / BM, (p.cout + BN - 1) / BN, batch);
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, p);
+    if (p.a_mode == A_NHWC) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, A_NHWC>), grid, dim3(256), 0, s, p);
+    else if (p.a_mode == A_UPS2X) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, A_UPS2X>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, A_GATHER>), grid, dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
@@ -445,7 +492,7 @@ hipError_t launch_conv(const ConvParams& p, int batch, hipStream_t s, int tile, 
         return hipErrorInvalidValue;
     if (!p.out || !p.w || !p.in[0]) return hipErrorInvalidValue;
     if (p.a_mode == A_GATHER) {
-        if (p.g_cin <= 0 || p.Ktot < p.KH * p.KW * p.g_cin) return hipErrorInvalidValue;
+        if (p.g_cin <= 0 || p.Ktot < p.KH * p.KW * p.g_cin || p.Ktot > 256 || p.KH > 255 || p.KW > 255) return hipErrorInvalidValue;
         if (p.Hin != p.Hsrc + p.g_offy || p.Win != p.Wsrc + p.g_offx) return hipErrorInvalidValue;
     } else {
         if (p.cin_pad <= 0 || (p.cin_pad % KC) != 0 || p.Ktot != p.KH * p.KW * p.cin_pad)

@@ -17,7 +17,7 @@ SYMBOLS = [
     "cf_create", "cf_destroy", "cf_last_error", "cf_workspace_bytes", "cf_load_weights",
     "cf_finalize_weights", "cf_warp", "cf_cista_forward", "cf_flow_forward", "cf_step",
     "cf_op_conv2d", "cf_op_instance_norm_relu", "cf_op_corr_lookup", "cf_op_nchw_to_nhwc",
-    "cf_op_nhwc_to_nchw", "cf_profile_enable", "cf_profile_read", "cf_conv_tile_name",
+    "cf_op_nhwc_to_nchw", "cf_profile_enable", "cf_profile_read", "cf_conv_tile_name", "cf_profile_report",
 ]
 
 
@@ -80,6 +80,8 @@ def load():
     lib.cf_profile_enable.restype = i
     lib.cf_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong), i]
     lib.cf_profile_read.restype = i
+    lib.cf_profile_report.argtypes = [vp]
+    lib.cf_profile_report.restype = C.c_char_p
     lib.cf_conv_tile_name.argtypes = [i]
     lib.cf_conv_tile_name.restype = C.c_char_p
     _lib = lib
@@ -156,6 +158,9 @@ class Handle:
             name = "conv_igemm_kernel<*>" if t == 0 else self.lib.cf_conv_tile_name(t).decode()
             out.append(dict(name=name, ms=ms[t], flops=fl[t], count=int(cnt[t])))
         return out
+
+    def profile_report(self):
+        return self.lib.cf_profile_report(self.h).decode()
 
     @property
     def workspace_bytes(self):

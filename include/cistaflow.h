@@ -104,6 +104,8 @@ int cf_step(cf_handle* h, const float* in0, const float* in1, const float* rec_i
 int cf_profile_enable(cf_handle* h, int on);
 int cf_profile_read(cf_handle* h, double* ms, double* flops, long long* count, int n);
 const char* cf_conv_tile_name(int tile);
+/* per-layer text table of the last cf_profile_read (layer, tile kind, launches, ms, TFLOP/s) */
+const char* cf_profile_report(const cf_handle* h);
 
 /* single-operator entry points (used by the parity tests; same kernels as the fused paths) ------ */
 /* conv2d on NHWC input (a_mode 0), fused x2-upsample input (a_mode 1) or planar NCHW small-Cin input
