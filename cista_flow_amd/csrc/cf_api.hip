@@ -522,7 +522,7 @@ extern "C" int cf_profile_enable(cf_handle* h, int on) {
 // Synchronises the recorded events, then for tile kind t = 1..6 (conv_igemm.hip) accumulates
 // ms[t] (sum of launch durations), flops[t] (sum of algorithmic flops), count[t]; index 0 = totals.
 extern "C" int cf_profile_read(cf_handle* h, double* ms, double* flops, long long* count, int n) {
-    if (!h || !ms || !flops || !count || n < 7) return CF_ERR_ARG;
+    if (!h || !ms || !flops || !count || n < 8) return CF_ERR_ARG;
     for (int i = 0; i < n; ++i) { ms[i] = 0; flops[i] = 0; count[i] = 0; }
     struct Agg { double ms = 0, flops = 0; long cnt = 0; int tile = 0; };
     std::map<std::string, Agg> agg;
@@ -530,7 +530,7 @@ extern "C" int cf_profile_read(cf_handle* h, double* ms, double* flops, long lon
         float t = 0.f;
         if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&t, r.a, r.b) != hipSuccess)
             return h->fail(CF_ERR_HIP, "cf_profile_read: event query failed");
-        const int k = (r.tile >= 1 && r.tile <= 6) ? r.tile : 0;
+        const int k = (r.tile >= 1 && r.tile < n) ? r.tile : 0;
         if (k) { ms[k] += t; flops[k] += r.flops; count[k] += 1; }
         ms[0] += t; flops[0] += r.flops; count[0] += 1;
         Agg& a = agg[r.tag ? r.tag : ""];
@@ -907,9 +907,9 @@ struct TmpBuf {
 };
 }  // namespace
 
-extern "C" int cf_op_conv2d(const float* in, int B, int Cin, int H, int W, const float* weight, const float* bias, int Cout,
-                            int KH, int KW, int stride, int padT, int padL, int pad_mode, int a_mode, int epi, int tile,
-                            float* out, void* stream) {
+static int op_conv2d_impl(const float* in, int B, int Cin, int H, int W, const float* weight, const float* bias, int Cout,
+                          int KH, int KW, int stride, int padT, int padL, int pad_mode, int a_mode, int epi, int tile,
+                          float* out, void* stream, int iters, float* ms_out) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (!in || !weight || !out || B < 1 || Cin < 1 || Cout < 1 || stride < 1) return CF_ERR_ARG;
     const bool gather = a_mode == A_GATHER;
@@ -945,8 +945,36 @@ extern "C" int cf_op_conv2d(const float* in, int B, int Cin, int H, int W, const
     }
     hipError_t e = launch_conv(p, B, st, tile);
     if (e != hipSuccess) return e == hipErrorInvalidValue ? CF_ERR_ARG : CF_ERR_HIP;
+    if (iters > 0 && ms_out) {   // timing loop for tools/conv_bench.py
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return CF_ERR_HIP;
+        (void)hipEventRecord(a, st);
+        for (int i = 0; i < iters; ++i) (void)launch_conv(p, B, st, tile);
+        (void)hipEventRecord(b, st);
+        (void)hipEventSynchronize(b);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, a, b);
+        *ms_out = ms / iters;
+        (void)hipEventDestroy(a);
+        (void)hipEventDestroy(b);
+    }
     if (hipStreamSynchronize(st) != hipSuccess) return CF_ERR_HIP;   // temp buffers die here
     return CF_OK;
+}
+
+extern "C" int cf_op_conv2d(const float* in, int B, int Cin, int H, int W, const float* weight, const float* bias, int Cout,
+                            int KH, int KW, int stride, int padT, int padL, int pad_mode, int a_mode, int epi, int tile,
+                            float* out, void* stream) {
+    return op_conv2d_impl(in, B, Cin, H, W, weight, bias, Cout, KH, KW, stride, padT, padL, pad_mode, a_mode, epi, tile, out,
+                          stream, 0, nullptr);
+}
+
+// same op launched `iters` times between two HIP events; *ms_out = average launch duration (tuning tool)
+extern "C" int cf_op_conv2d_bench(const float* in, int B, int Cin, int H, int W, const float* weight, const float* bias,
+                                  int Cout, int KH, int KW, int stride, int padT, int padL, int pad_mode, int a_mode,
+                                  int epi, int tile, float* out, void* stream, int iters, float* ms_out) {
+    return op_conv2d_impl(in, B, Cin, H, W, weight, bias, Cout, KH, KW, stride, padT, padL, pad_mode, a_mode, epi, tile, out,
+                          stream, iters, ms_out);
 }
 
 extern "C" int cf_op_instance_norm_relu(const float* x, float* out, int B, int C, int H, int W, float eps, void* stream) {

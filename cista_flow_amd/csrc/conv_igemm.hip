@@ -474,6 +474,87 @@ static hipError_t launch_t(const ConvParams& p, int batch, hipStream_t s) {
 }
 
 // tile ids: 1 = 128x128, 2 = 128x64, 3 = 128x96, 4 = 64x64, 5 = 64x128, 6 = 128x32
+// ---------------------------------------------------------------------------
+// Convolutions with 1-2 output channels (FlowHead.conv2 256->2, final_conv 64->1): on the matrix
+// cores they would waste 31/32 of every tile, and their M x K work is tiny, so they run on the vector
+// ALUs instead: LPP = Cin/4 adjacent lanes share one output pixel (each lane owns 4 input channels and
+// does 16-byte loads), every tap is one coalesced row read, and the lane group is folded with
+// wave shuffles.  HBM-bound by construction (reads the input once per tap through L1/L2).
+// ---------------------------------------------------------------------------
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_smalln_kernel(const ConvParams p, int lpp) {
+    const int tid = threadIdx.x;
+    const int g = tid / lpp;                 // pixel slot inside the workgroup
+    const int ppw = 256 / lpp;               // pixels per workgroup
+    const int c0 = (tid - g * lpp) * 4;
+    const int b = blockIdx.y;
+    const int M = p.Ho * p.Wo;
+    const int m = blockIdx.x * ppw + g;
+    const bool live = m < M;
+    const int oy = live ? m / p.Wo : 0;
+    const int ox = live ? m - oy * p.Wo : 0;
+    const float* src = p.in[0] + (long)b * p.seg_bs[0] + c0;
+    float acc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
+    for (int ky = 0; ky < p.KH; ++ky) {
+        for (int kx = 0; kx < p.KW; ++kx) {
+            int iy = oy * p.stride + ky - p.padT;
+            int ix = ox * p.stride + kx - p.padL;
+            bool ok = live;
+            if (p.pad_mode == 1) {
+                iy = reflect_idx(iy, p.Hin);
+                ix = reflect_idx(ix, p.Win);
+            } else {
+                ok = ok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+            }
+            if (ok) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(src + ((long)iy * p.Win + ix) * p.seg_ld[0]);
+                const int koff = (ky * p.KW + kx) * p.cin_pad + c0;
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(p.w + (long)co * p.Ktot + koff);
+                    acc[co] += v[0] * w[0] + v[1] * w[1] + v[2] * w[2] + v[3] * w[3];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+        float a = acc[co];
+        for (int off = lpp >> 1; off > 0; off >>= 1) a += __shfl_xor(a, off);
+        acc[co] = a;
+    }
+    if (live && c0 == 0) {
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            float v = acc[co] + (p.bias ? p.bias[co] : 0.f);
+            const long ooff = (long)b * p.out_bs + (long)m * p.out_ld + (long)co * p.out_cs;
+            if (p.epi == EPI_SIGMOID) v = sigmoidf_(v);
+            else if (p.epi == EPI_RELU) v = fmaxf(v, 0.f);
+            else if (p.epi == EPI_TANH) v = tanhf(v);
+            else if (p.epi == EPI_ADD_AUX) v += p.aux0[(long)b * p.aux0_bs + (long)m * p.aux0_ld + (long)co * p.aux0_cs];
+            p.out[ooff] = v;
+        }
+    }
+}
+
+static bool smalln_ok(const ConvParams& p) {
+    if (p.a_mode != A_NHWC || p.nseg != 1 || p.cout > 2 || p.w_bs != 0) return false;
+    if (p.cin_pad != 64 && p.cin_pad != 128 && p.cin_pad != 256) return false;
+    return p.epi == EPI_NONE || p.epi == EPI_SIGMOID || p.epi == EPI_RELU || p.epi == EPI_TANH || p.epi == EPI_ADD_AUX;
+}
+
+static hipError_t launch_smalln(const ConvParams& p, int batch, hipStream_t s) {
+    const int lpp = p.cin_pad / 4;
+    const int ppw = 256 / lpp;
+    const int M = p.Ho * p.Wo;
+    dim3 grid((M + ppw - 1) / ppw, batch);
+    if (p.cout == 1) hipLaunchKernelGGL(conv_smalln_kernel<1>, grid, dim3(256), 0, s, p, lpp);
+    else hipLaunchKernelGGL(conv_smalln_kernel<2>, grid, dim3(256), 0, s, p, lpp);
+    return hipGetLastError();
+}
+
 const char* conv_tile_name(int tile) {
     switch (tile) {
         case 1: return "conv_igemm_kernel<128,128,2,2>";
@@ -482,6 +563,7 @@ const char* conv_tile_name(int tile) {
         case 4: return "conv_igemm_kernel<64,64,2,2>";
         case 5: return "conv_igemm_kernel<64,128,2,2>";
         case 6: return "conv_igemm_kernel<128,32,4,1>";
+        case 7: return "conv_smalln_kernel";
         default: return "?";
     }
 }
@@ -517,6 +599,12 @@ hipError_t launch_conv(const ConvParams& p, int batch, hipStream_t s, int tile, 
     if ((p.Ho - 1) * p.stride - p.padT + 0 >= p.Hin || (p.Wo - 1) * p.stride - p.padL >= p.Win)
         return hipErrorInvalidValue;
 
+    if (tile == 0 && smalln_ok(p)) tile = 7;
+    if (tile == 7) {
+        if (!smalln_ok(p)) return hipErrorInvalidValue;
+        if (tile_used) *tile_used = 7;
+        return launch_smalln(p, batch, s);
+    }
     if (tile == 0) {
         const int M = p.Ho * p.Wo;
         int bn;
@@ -525,8 +613,10 @@ hipError_t launch_conv(const ConvParams& p, int batch, hipStream_t s, int tile, 
         else if ((p.cout % 96) == 0 && (p.cout % 128) != 0) bn = 96;
         else bn = 128;
         const long wg128 = (long)((M + 127) / 128) * ((p.cout + bn - 1) / bn) * batch;
+        // measured on MI355X (tools/conv_bench.py): below ~512 workgroups the 64x64 tile wins even when it
+        // pads cout (96 -> 128), because the 128-row tiles leave most CUs idle
         if (bn == 32) tile = 6;
-        else if (bn == 96) tile = 3;
+        else if (bn == 96) tile = (wg128 >= 512) ? 3 : 4;
         else if (bn == 64) tile = (wg128 >= 512) ? 2 : 4;
         else tile = (wg128 >= 512) ? 1 : ((long)((M + 63) / 64) * ((p.cout + 127) / 128) * batch >= 512 ? 5 : 4);
     }

@@ -162,35 +162,46 @@ hipError_t launch_any_nonzero(const float* x, long n, int* flag, hipStream_t s) 
 // stage 1: per (image, pixel-chunk) partial {sum, sum of squares} in fp64 for every channel
 // stage 2: fold the chunks -> {mean, rstd}
 // ---------------------------------------------------------------------------
-static constexpr int IN_CHUNK = 512;   // pixels per stage-1 workgroup
+static constexpr int IN_CHUNK = 256;   // pixels per stage-1 workgroup
 
+// one thread = 4 consecutive channels (16-byte loads); the C/4 channel quads of a pixel sit in adjacent
+// lanes so every wave load covers whole 128-byte rows; partial sums are kept in fp64
 __global__ __launch_bounds__(256) void inorm_partial_kernel(const float* __restrict__ x, int ld, long bs, int HW, int C,
                                                             double* __restrict__ partial, int nchunk) {
-    __shared__ double sh[2 * 256];
+    __shared__ double sh[256 * 8];
     const int b = blockIdx.y, ch = blockIdx.x;
     const int tid = threadIdx.x;
-    const int tpc = 256 / C >= 1 ? 256 / C : 1;   // pixel lanes per channel (C <= 256)
-    const int c = tid % C;
-    const int pl = tid / C;
-    double s = 0.0, ss = 0.0;
-    if (pl < tpc) {
+    const int cq = C >> 2;              // channel quads per pixel (16, 24, 32)
+    const int ppp = 256 / cq;           // pixels per pass
+    const int pl = tid / cq;
+    const int q = tid - pl * cq;
+    double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    if (pl < ppp) {
         const int p0 = ch * IN_CHUNK;
         const int p1 = min(HW, p0 + IN_CHUNK);
-        const float* xb = x + (long)b * bs;
-        for (int p = p0 + pl; p < p1; p += tpc) {
-            const double v = (double)xb[(long)p * ld + c];
-            s += v;
-            ss += v * v;
+        const float* xb = x + (long)b * bs + q * 4;
+        for (int p = p0 + pl; p < p1; p += ppp) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (long)p * ld);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const double d = (double)v[e];
+                s[e] += d;
+                ss[e] += d * d;
+            }
         }
     }
-    sh[tid] = s;
-    sh[256 + tid] = ss;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        sh[tid * 8 + e] = s[e];
+        sh[tid * 8 + 4 + e] = ss[e];
+    }
     __syncthreads();
     if (tid < C) {
+        const int qq = tid >> 2, e = tid & 3;
         double a = 0.0, aa = 0.0;
-        for (int k = 0; k < tpc; ++k) {
-            a += sh[k * C + tid];
-            aa += sh[256 + k * C + tid];
+        for (int k = 0; k < ppp; ++k) {
+            a += sh[(k * cq + qq) * 8 + e];
+            aa += sh[(k * cq + qq) * 8 + 4 + e];
         }
         double* dst = partial + (((long)b * nchunk + ch) * C + tid) * 2;
         dst[0] = a;
@@ -218,7 +229,9 @@ __global__ void inorm_final_kernel(const double* __restrict__ partial, int nchun
 
 hipError_t launch_inorm_stats(const float* x, int ld, long bs, int B, int HW, int C, float eps, double* partial,
                               float* stats, hipStream_t s) {
-    if (!x || !partial || !stats || C <= 0 || C > 256 || B <= 0 || HW <= 0 || ld < C) return hipErrorInvalidValue;
+    if (!x || !partial || !stats || C <= 0 || C > 256 || (C % 4) != 0 || (ld % 4) != 0 || (bs % 4) != 0 || B <= 0 || HW <= 0 || ld < C ||
+        (reinterpret_cast<uintptr_t>(x) & 15) != 0)
+        return hipErrorInvalidValue;
     const int nchunk = (HW + IN_CHUNK - 1) / IN_CHUNK;
     hipLaunchKernelGGL(inorm_partial_kernel, dim3(nchunk, B), dim3(256), 0, s, x, ld, bs, HW, C, partial, nchunk);
     hipError_t e = hipGetLastError();

@@ -17,7 +17,7 @@ SYMBOLS = [
     "cf_create", "cf_destroy", "cf_last_error", "cf_workspace_bytes", "cf_load_weights",
     "cf_finalize_weights", "cf_warp", "cf_cista_forward", "cf_flow_forward", "cf_step",
     "cf_op_conv2d", "cf_op_instance_norm_relu", "cf_op_corr_lookup", "cf_op_nchw_to_nhwc",
-    "cf_op_nhwc_to_nchw", "cf_profile_enable", "cf_profile_read", "cf_conv_tile_name", "cf_profile_report",
+    "cf_op_nhwc_to_nchw", "cf_profile_enable", "cf_profile_read", "cf_conv_tile_name", "cf_profile_report", "cf_op_conv2d_bench",
 ]
 
 
@@ -68,6 +68,8 @@ def load():
     lib.cf_step.restype = i
     lib.cf_op_conv2d.argtypes = [fp, i, i, i, i, fp, fp, i, i, i, i, i, i, i, i, i, i, fp, vp]
     lib.cf_op_conv2d.restype = i
+    lib.cf_op_conv2d_bench.argtypes = [fp, i, i, i, i, fp, fp, i, i, i, i, i, i, i, i, i, i, fp, vp, i, C.POINTER(C.c_float)]
+    lib.cf_op_conv2d_bench.restype = i
     lib.cf_op_instance_norm_relu.argtypes = [fp, fp, i, i, i, i, C.c_float, vp]
     lib.cf_op_instance_norm_relu.restype = i
     lib.cf_op_corr_lookup.argtypes = [fp, fp, fp, fp, i, i, i, i, vp]
@@ -150,7 +152,7 @@ class Handle:
 
     def profile_read(self):
         """-> list of dicts per conv tile kind: name, ms, flops, count (index 0 = all conv launches)."""
-        n = 7
+        n = 8
         ms, fl, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_longlong * n)()
         self.check(self.lib.cf_profile_read(self.h, ms, fl, cnt, n), "cf_profile_read")
         out = []

@@ -113,6 +113,10 @@ const char* cf_profile_report(const cf_handle* h);
 int cf_op_conv2d(const float* in, int B, int Cin, int H, int W, const float* weight, const float* bias, int Cout,
                  int KH, int KW, int stride, int padT, int padL, int pad_mode, int a_mode, int epi, int tile,
                  float* out, void* stream);
+/* tuning tool: the same conv launched `iters` times between two HIP events; *ms_out = avg launch ms */
+int cf_op_conv2d_bench(const float* in, int B, int Cin, int H, int W, const float* weight, const float* bias, int Cout,
+                       int KH, int KW, int stride, int padT, int padL, int pad_mode, int a_mode, int epi, int tile,
+                       float* out, void* stream, int iters, float* ms_out);
 int cf_op_instance_norm_relu(const float* x_nhwc, float* out_nhwc, int B, int C, int H, int W, float eps,
                              void* stream);
 /* all-pairs correlation + pyramid + lookup (a9/a10): fmaps NHWC [B][h][w][D], coords NCHW [B][2][h][w];

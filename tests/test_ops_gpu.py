@@ -74,6 +74,11 @@ CONV_CASES = [
     (64, 128, 3, 3, 1, 1, 1, 1, 4),
     (64, 128, 3, 3, 1, 1, 1, 1, 5),
     (64, 128, 3, 3, 1, 1, 1, 1, 6),
+    (256, 2, 3, 3, 1, 1, 1, 0, 6),     # small-cout layers forced through the MFMA path
+    (64, 1, 3, 3, 1, 1, 1, 1, 6),
+    (256, 2, 3, 3, 1, 1, 1, 0, 7),     # ... and through the VALU small-N kernel explicitly
+    (64, 1, 3, 3, 1, 1, 1, 1, 7),
+    (128, 2, 3, 3, 1, 1, 1, 0, 7),
 ]
 
 

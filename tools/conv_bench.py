@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the implicit-GEMM conv kernel over tile shapes (tuning tool, GPU box only).
+
+    python tools/conv_bench.py            # the layer shapes of cista-eiflow at 180x240, B=8
+"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from cista_flow_amd import lib  # noqa: E402
+
+L = lib.load()
+dev = torch.device("cuda:0")
+
+# name, B, Cin, H, W, Cout, KH, KW, stride, padT, padL, pad_mode
+SHAPES = [
+    ("gru.zr    384->256 1x5 @24x32", 8, 384, 24, 32, 256, 1, 5, 1, 0, 2, 0),
+    ("gru.q     384->128 1x5 @24x32", 8, 384, 24, 32, 128, 1, 5, 1, 0, 2, 0),
+    ("convc2    256->192 3x3 @24x32", 8, 256, 24, 32, 192, 3, 3, 1, 1, 1, 0),
+    ("menc      320->128 3x3 @24x32", 8, 320, 24, 32, 128, 3, 3, 1, 1, 1, 0),
+    ("fh.conv1  128->256 3x3 @24x32", 8, 128, 24, 32, 256, 3, 3, 1, 1, 1, 0),
+    ("layer3    128->128 3x3 @24x32", 8, 128, 24, 32, 128, 3, 3, 1, 1, 1, 0),
+    ("layer2     96->96  3x3 @48x64", 8, 96, 48, 64, 96, 3, 3, 1, 1, 1, 0),
+    ("layer1     64->64  3x3 @96x128", 8, 64, 96, 128, 64, 3, 3, 1, 1, 1, 0),
+    ("cista.D   128->64  3x3 @90x120", 8, 128, 90, 120, 64, 3, 3, 1, 1, 1, 1),
+    ("cista.P    64->128 3x3 @90x120", 8, 64, 90, 120, 128, 3, 3, 1, 1, 1, 1),
+    ("gates     192->256 3x3 @90x120", 8, 192, 90, 120, 256, 3, 3, 1, 1, 1, 1),
+]
+
+
+def run(shape, tile, iters=20):
+    name, B, Cin, H, W, Cout, KH, KW, stride, pT, pL, pm = shape
+    x = torch.randn(B, H, W, Cin, device=dev)
+    w = torch.randn(Cout, Cin, KH, KW, device=dev) / (Cin * KH * KW) ** 0.5
+    b = torch.randn(Cout, device=dev)
+    Ho = (H + 2 * pT - KH) // stride + 1
+    Wo = (W + 2 * pL - KW) // stride + 1
+    out = torch.empty(B, Ho, Wo, Cout, device=dev)
+    ms = C.c_float(0)
+    rc = L.cf_op_conv2d_bench(lib.ptr(x), B, Cin, H, W, lib.ptr(w), lib.ptr(b), Cout, KH, KW, stride, pT, pL, pm, 0, 0,
+                              tile, lib.ptr(out), lib.current_stream_ptr(), iters, C.byref(ms))
+    if rc != 0:
+        return None
+    flops = 2.0 * B * Ho * Wo * Cout * Cin * KH * KW
+    return ms.value * 1e3, flops / (ms.value * 1e-3) / 1e12
+
+
+def main():
+    tiles = [int(t) for t in os.environ.get("TILES", "0,1,2,3,4,5,6").split(",")]
+    for sh in SHAPES:
+        res = []
+        for t in tiles:
+            r = run(sh, t)
+            res.append("t%d: %s" % (t, "n/a" if r is None else "%7.1fus %5.1fTF" % r))
+        print("%-32s %s" % (sh[0], " | ".join(res)), flush=True)
+
+
+if __name__ == "__main__":
+    main()
