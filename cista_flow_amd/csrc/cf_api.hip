@@ -94,6 +94,7 @@ struct cf_handle {
     int clh[4] = {0, 0, 0, 0}, clw[4] = {0, 0, 0, 0};
     float *coords1 = nullptr, *corrfeat = nullptr, *c1buf = nullptr, *mcat = nullptr, *e1buf = nullptr, *f1buf = nullptr,
           *motion = nullptr, *zbuf = nullptr, *rh = nullptr, *fh = nullptr;
+    float* gpre[2] = {nullptr, nullptr};
     static constexpr int CORR_LD = 336;   // 4*81 = 324 correlation channels padded to a multiple of 16
 
     // per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
@@ -194,6 +195,8 @@ static void setup_buffers(cf_handle* H_) {
         s.zbuf = a.f(B * N * 128);
         s.rh = a.f(B * N * 128);
         s.fh = a.f(B * N * 256);
+        s.gpre[0] = a.f(B * N * 384);
+        s.gpre[1] = a.f(B * N * 384);
     }
 }
 
@@ -273,20 +276,27 @@ static const RawWeight* find_raw(cf_handle* h, const std::string& name) {
     return it == h->raw.end() ? nullptr : &it->second;
 }
 
+struct CinSlice { int begin, count, dst; };
+
 // Packs `prefix`.weight/.bias (OIHW) as rows [row0, row0+Cout) of the conv registered under `key`.
 // total_rows > 0 on the first call allocates the packed matrix; bn_prefix folds an eval BatchNorm.
+// slices (optional): input-channel ranges of the source laid out at `dst` inside a packed_cin-wide K block
+// (used to split a layer into its iteration-invariant and per-iteration parts); with_bias=false drops the bias.
 static int pack_conv(cf_handle* h, const std::string& key, const std::string& prefix, bool gather, int row0,
-                     int total_rows, const std::string& bn_prefix, hipStream_t st) {
+                     int total_rows, const std::string& bn_prefix, hipStream_t st,
+                     const std::vector<CinSlice>& slices = {}, int packed_cin = 0, bool with_bias = true) {
     const RawWeight* wt = find_raw(h, prefix + ".weight");
     const RawWeight* bs = find_raw(h, prefix + ".bias");
     if (!wt || wt->shape.size() != 4) return h->fail(CF_ERR_WEIGHT, "missing or non-4D weight: " + prefix + ".weight");
     const int Cout = (int)wt->shape[0], Cin = (int)wt->shape[1], KH = (int)wt->shape[2], KW = (int)wt->shape[3];
     if (bs && (bs->shape.size() != 1 || bs->shape[0] != Cout)) return h->fail(CF_ERR_WEIGHT, "bad bias shape: " + prefix);
+    const int cin_eff = slices.empty() ? Cin : packed_cin;
+    if (!slices.empty() && (gather || packed_cin <= 0)) return h->fail(CF_ERR_WEIGHT, "bad slice spec: " + prefix);
     PackedConv& pc = h->conv[key];
     pc.name = key;
     if (!pc.w) {
-        pc.cin = Cin; pc.KH = KH; pc.KW = KW; pc.gather = gather;
-        pc.cin_pad = gather ? 0 : round_up(Cin, 16);
+        pc.cin = cin_eff; pc.KH = KH; pc.KW = KW; pc.gather = gather;
+        pc.cin_pad = gather ? 0 : round_up(cin_eff, 16);
         pc.Ktot = gather ? round_up(KH * KW * Cin, 16) : KH * KW * pc.cin_pad;
         pc.cout = total_rows > 0 ? total_rows : Cout;
         pc.rows = round_up(pc.cout, 128);
@@ -298,7 +308,7 @@ static int pack_conv(cf_handle* h, const std::string& key, const std::string& pr
         CF_HIP(h, hipMemsetAsync(pc.w, 0, wbytes, st));
         CF_HIP(h, hipMemsetAsync(pc.bias, 0, pc.rows * sizeof(float), st));
     } else {
-        if (pc.cin != Cin || pc.KH != KH || pc.KW != KW) return h->fail(CF_ERR_WEIGHT, "stacked conv shape mismatch: " + prefix);
+        if (pc.cin != cin_eff || pc.KH != KH || pc.KW != KW) return h->fail(CF_ERR_WEIGHT, "stacked conv shape mismatch: " + prefix);
     }
     if (row0 + Cout > pc.rows) return h->fail(CF_ERR_WEIGHT, "stacked conv overflows: " + prefix);
     const float *bw = nullptr, *bb = nullptr, *bm = nullptr, *bv = nullptr;
@@ -312,8 +322,15 @@ static int pack_conv(cf_handle* h, const std::string& key, const std::string& pr
             return h->fail(CF_ERR_WEIGHT, "bad BatchNorm shape: " + bn_prefix);
         bw = r0->ptr; bb = r1->ptr; bm = r2->ptr; bv = r3->ptr;
     }
-    CF_HIP(h, launch_pack_weight(wt->ptr, pc.w, Cout, Cin, KH, KW, pc.cin_pad, pc.Ktot, row0, gather ? 1 : 0, bw, bb, bm,
-                                 bv, 1e-5f, bs ? bs->ptr : nullptr, pc.bias, st));
+    const float* bsrc = (bs && with_bias) ? bs->ptr : nullptr;
+    if (slices.empty()) {
+        CF_HIP(h, launch_pack_weight(wt->ptr, pc.w, Cout, Cin, KH, KW, pc.cin_pad, pc.Ktot, row0, gather ? 1 : 0, 0, 0, 0, bw,
+                                     bb, bm, bv, 1e-5f, bsrc, pc.bias, st));
+    } else {
+        for (const CinSlice& sl : slices)
+            CF_HIP(h, launch_pack_weight(wt->ptr, pc.w, Cout, Cin, KH, KW, pc.cin_pad, pc.Ktot, row0, 0, sl.begin, sl.count,
+                                         sl.dst, bw, bb, bm, bv, 1e-5f, bsrc, pc.bias, st));
+    }
     return CF_OK;
 }
 
@@ -412,13 +429,21 @@ extern "C" int cf_finalize_weights(cf_handle* h, void* stream) {
         if ((rc = F("convf2", e + "convf2", false))) return rc;
         if ((rc = F("menc.conv", e + "conv", false))) return rc;
         const std::string g = f + "update_block.gru.";
-        // z | r stacked into one 256-row matrix per pass (with_event_updater.py:54-65)
-        if ((rc = pack_conv(h, "gru.zr1", g + "convz1", false, 0, 256, "", st))) return rc;
-        if ((rc = pack_conv(h, "gru.zr1", g + "convr1", false, 128, 256, "", st))) return rc;
-        if ((rc = pack_conv(h, "gru.q1", g + "convq1", false, 0, 0, "", st))) return rc;
-        if ((rc = pack_conv(h, "gru.zr2", g + "convz2", false, 0, 256, "", st))) return rc;
-        if ((rc = pack_conv(h, "gru.zr2", g + "convr2", false, 128, 256, "", st))) return rc;
-        if ((rc = pack_conv(h, "gru.q2", g + "convq2", false, 0, 0, "", st))) return rc;
+        // SepConvGRU (with_event_updater.py:52-67), hx = cat(h, inp, motion).  Each conv is linear, so its
+        // `inp` slice (channels 128..255, iteration-invariant) is split off into gru.preN (z | r | q stacked,
+        // bias included) and evaluated once per frame; the per-iteration matrices keep h | motion only, with
+        // z | r stacked into one 256-row GEMM.
+        const std::vector<CinSlice> dyn = {{0, 128, 0}, {256, 128, 128}};
+        const std::vector<CinSlice> inv = {{128, 128, 0}};
+        for (int pass = 1; pass <= 2; ++pass) {
+            const std::string n = std::to_string(pass);
+            if ((rc = pack_conv(h, "gru.zr" + n, g + "convz" + n, false, 0, 256, "", st, dyn, 256, false))) return rc;
+            if ((rc = pack_conv(h, "gru.zr" + n, g + "convr" + n, false, 128, 256, "", st, dyn, 256, false))) return rc;
+            if ((rc = pack_conv(h, "gru.q" + n, g + "convq" + n, false, 0, 0, "", st, dyn, 256, false))) return rc;
+            if ((rc = pack_conv(h, "gru.pre" + n, g + "convz" + n, false, 0, 384, "", st, inv, 128, true))) return rc;
+            if ((rc = pack_conv(h, "gru.pre" + n, g + "convr" + n, false, 128, 384, "", st, inv, 128, true))) return rc;
+            if ((rc = pack_conv(h, "gru.pre" + n, g + "convq" + n, false, 256, 384, "", st, inv, 128, true))) return rc;
+        }
         if ((rc = F("fh.conv1", "update_block.flow_head.conv1", false))) return rc;
         if ((rc = F("fh.conv2", "update_block.flow_head.conv2", false))) return rc;
         if (h->conv["convc1"].cin_pad != cf_handle::CORR_LD) return h->fail(CF_ERR_WEIGHT, "convc1 expects 324 input channels");
@@ -792,6 +817,12 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
         ConvParams b = nhwc_conv(h->conv["conve2"], {{h->e1buf, 128, 128, N * 128}}, h8, w8, h8, w8, 1, 1, 1, 0, h->mcat + 192, 320, N * 320, EPI_RELU);
         CF_HIP(h, run_conv(h, b, B, st));
     }
+    // iteration-invariant `inp` contribution of the six GRU convolutions (z | r | q stacked per pass)
+    for (int pass = 0; pass < 2; ++pass) {
+        const int pT = pass == 0 ? 0 : 2, pL = pass == 0 ? 2 : 0;
+        ConvParams g = nhwc_conv(h->conv[pass == 0 ? "gru.pre1" : "gru.pre2"], {{h->inp, 128, 128, N * 128}}, h8, w8, h8, w8, 1, pT, pL, 0, h->gpre[pass], 384, N * 384, EPI_NONE);
+        CF_HIP(h, run_conv(h, g, B, st));
+    }
     CF_HIP(h, launch_coords_init(h->coords1, flow_init, B, h8, w8, st));
     if (flag) CF_HIP(h, hipMemsetAsync(flag, 0, sizeof(int), st));
     const int iters = h->cfg.iters;
@@ -814,17 +845,22 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
         CF_HIP(h, run_conv(h, f2, B, st));
         ConvParams mc = nhwc_conv(h->conv["menc.conv"], {{h->mcat, 320, 320, N * 320}}, h8, w8, h8, w8, 1, 1, 1, 0, h->motion, 128, N * 128, EPI_RELU);
         CF_HIP(h, run_conv(h, mc, B, st));
-        // SepConvGRU  with_event_updater.py:52-67 ; hx = cat(h, inp, motion)
+        // SepConvGRU  with_event_updater.py:52-67 ; hx = cat(h, inp, motion), inp part precomputed (gpre)
         for (int pass = 0; pass < 2; ++pass) {
             const PackedConv& zr = h->conv[pass == 0 ? "gru.zr1" : "gru.zr2"];
             const PackedConv& qq = h->conv[pass == 0 ? "gru.q1" : "gru.q2"];
+            const float* pre = h->gpre[pass];
             const int pT = pass == 0 ? 0 : 2, pL = pass == 0 ? 2 : 0;
-            ConvParams a = nhwc_conv(zr, {{h->net, 128, 128, N * 128}, {h->inp, 128, 128, N * 128}, {h->motion, 128, 128, N * 128}}, h8, w8, h8, w8, 1, pT, pL, 0, h->zbuf, 128, N * 128, EPI_GRU_ZR);
+            ConvParams a = nhwc_conv(zr, {{h->net, 128, 128, N * 128}, {h->motion, 128, 128, N * 128}}, h8, w8, h8, w8, 1, pT, pL, 0, h->zbuf, 128, N * 128, EPI_GRU_ZR);
             a.split = 128;
+            a.bias = nullptr;
+            a.addend = pre; a.addend_ld = 384; a.addend_bs = N * 384;
             set_aux0(a, h->net, 128, N * 128);
             set_out2(a, h->rh, 128, N * 128);
             CF_HIP(h, run_conv(h, a, B, st));
-            ConvParams q = nhwc_conv(qq, {{h->rh, 128, 128, N * 128}, {h->inp, 128, 128, N * 128}, {h->motion, 128, 128, N * 128}}, h8, w8, h8, w8, 1, pT, pL, 0, h->net, 128, N * 128, EPI_GRU_Q);
+            ConvParams q = nhwc_conv(qq, {{h->rh, 128, 128, N * 128}, {h->motion, 128, 128, N * 128}}, h8, w8, h8, w8, 1, pT, pL, 0, h->net, 128, N * 128, EPI_GRU_Q);
+            q.bias = nullptr;
+            q.addend = pre + 256; q.addend_ld = 384; q.addend_bs = N * 384;
             set_aux0(q, h->zbuf, 128, N * 128);
             set_aux1(q, h->net, 128, N * 128);
             CF_HIP(h, run_conv(h, q, B, st));
@@ -928,7 +964,7 @@ static int op_conv2d_impl(const float* in, int B, int Cin, int H, int W, const f
     pc.bias = static_cast<float*>(bb.p);
     if (hipMemsetAsync(pc.w, 0, (size_t)pc.rows * pc.Ktot * sizeof(float), st) != hipSuccess) return CF_ERR_HIP;
     if (hipMemsetAsync(pc.bias, 0, pc.rows * sizeof(float), st) != hipSuccess) return CF_ERR_HIP;
-    if (launch_pack_weight(weight, pc.w, Cout, Cin, KH, KW, pc.cin_pad, pc.Ktot, 0, gather ? 1 : 0, nullptr, nullptr, nullptr,
+    if (launch_pack_weight(weight, pc.w, Cout, Cin, KH, KW, pc.cin_pad, pc.Ktot, 0, gather ? 1 : 0, 0, 0, 0, nullptr, nullptr, nullptr,
                            nullptr, 0.f, bias, pc.bias, st) != hipSuccess)
         return CF_ERR_HIP;
     ConvParams p;

@@ -78,6 +78,7 @@ struct ConvParams {
     const float* aux2; int aux2_ld; long aux2_bs;
     const float* aux3; int aux3_ld; long aux3_bs;
     const float* lam;   // [cout] soft-threshold
+    const float* addend; int addend_ld; long addend_bs;   // v += addend[b][m][n] before the epilogue op
     int  k_real;        // un-padded K (taps * Cin): algorithmic-flop bookkeeping only
     const char* tag;    // layer name for the profiler (host side only)
 };
@@ -92,8 +93,9 @@ const char* conv_tile_name(int tile);
 // src: OIHW [Cout][Cin][KH][KW]  ->  dst rows [row0 .. row0+Cout) of [rows][Ktot]
 //   gather==0: k = tap*cin_pad + c ; gather==1: k = tap*Cin + c
 // optional BatchNorm fold (eval): w' = w*g/sqrt(var+eps), b' = (b-mean)*g/sqrt(var+eps)+beta
+// c_begin/c_count select an input-channel slice of src (c_count <= 0: all), written at channel dst_coff.
 hipError_t launch_pack_weight(const float* src, float* dst, int Cout, int Cin, int KH, int KW,
-                              int cin_pad, int Ktot, int row0, int gather,
+                              int cin_pad, int Ktot, int row0, int gather, int c_begin, int c_count, int dst_coff,
                               const float* bn_w, const float* bn_b, const float* bn_mean,
                               const float* bn_var, float bn_eps,
                               const float* bias_src, float* bias_dst, hipStream_t s);

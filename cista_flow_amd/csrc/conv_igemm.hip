@@ -53,6 +53,11 @@ __device__ __forceinline__ void epilogue4(const ConvParams& p, int b, int m, int
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += (e < nv) ? p.bias[n + e] : 0.f;
     }
+    if (p.addend) {   // iteration-invariant part of a linear layer, precomputed once per frame
+        const long aoff = (long)b * p.addend_bs + (long)m * p.addend_ld + n;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (e < nv) ? p.addend[aoff + e] : 0.f;
+    }
     const long ooff = (long)b * p.out_bs + (long)m * p.out_ld + (long)n * p.out_cs;
     const bool ovec = full && p.out_cs == 1 && ((ooff & 3) == 0);
     f32x4 o = v;
@@ -636,22 +641,23 @@ hipError_t launch_conv(const ConvParams& p, int batch, hipStream_t s, int tile, 
 // weight packing
 // ---------------------------------------------------------------------------
 __global__ void pack_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int Cin,
-                                   int KH, int KW, int cin_pad, int Ktot, int row0, int gather,
-                                   const float* bn_w, const float* bn_b, const float* bn_mean,
-                                   const float* bn_var, float bn_eps, const float* bias_src, float* bias_dst) {
-    const long total = (long)Cout * Cin * KH * KW;
+                                   int KH, int KW, int cin_pad, int Ktot, int row0, int gather, int c_begin,
+                                   int c_count, int dst_coff, const float* bn_w, const float* bn_b,
+                                   const float* bn_mean, const float* bn_var, float bn_eps, const float* bias_src,
+                                   float* bias_dst) {
+    const long total = (long)Cout * c_count * KH * KW;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < total) {
         const int kw = idx % KW;
         long t = idx / KW;
         const int kh = t % KH;
         t /= KH;
-        const int c = t % Cin;
-        const int o = (int)(t / Cin);
-        float v = src[idx];
+        const int c = t % c_count;
+        const int o = (int)(t / c_count);
+        float v = src[(((long)o * Cin + (c_begin + c)) * KH + kh) * KW + kw];
         if (bn_var) v *= bn_w[o] / sqrtf(bn_var[o] + bn_eps);
         const int tap = kh * KW + kw;
-        const long k = gather ? ((long)tap * Cin + c) : ((long)tap * cin_pad + c);
+        const long k = gather ? ((long)tap * c_count + c) : ((long)tap * cin_pad + dst_coff + c);
         dst[(long)(row0 + o) * Ktot + k] = v;
     }
     if (idx < Cout && bias_dst) {
@@ -663,20 +669,22 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, float* __restr
 }
 
 hipError_t launch_pack_weight(const float* src, float* dst, int Cout, int Cin, int KH, int KW, int cin_pad,
-                              int Ktot, int row0, int gather, const float* bn_w, const float* bn_b,
-                              const float* bn_mean, const float* bn_var, float bn_eps, const float* bias_src,
-                              float* bias_dst, hipStream_t s) {
-    const long total = (long)Cout * Cin * KH * KW;
-    if (total <= 0) return hipErrorInvalidValue;
+                              int Ktot, int row0, int gather, int c_begin, int c_count, int dst_coff,
+                              const float* bn_w, const float* bn_b, const float* bn_mean, const float* bn_var,
+                              float bn_eps, const float* bias_src, float* bias_dst, hipStream_t s) {
+    if (c_count <= 0) { c_begin = 0; c_count = Cin; }
+    const long total = (long)Cout * c_count * KH * KW;
+    if (total <= 0 || c_begin < 0 || c_begin + c_count > Cin || dst_coff < 0) return hipErrorInvalidValue;
     if (gather) {
-        if (Ktot < KH * KW * Cin) return hipErrorInvalidValue;
+        if (Ktot < KH * KW * c_count || c_begin != 0 || dst_coff != 0) return hipErrorInvalidValue;
     } else {
-        if (cin_pad < Cin || Ktot != KH * KW * cin_pad) return hipErrorInvalidValue;
+        if (cin_pad < dst_coff + c_count || Ktot != KH * KW * cin_pad) return hipErrorInvalidValue;
     }
     const int threads = 256;
     const long blocks = (total + threads - 1) / threads;
     hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)blocks), dim3(threads), 0, s, src, dst, Cout, Cin, KH, KW,
-                       cin_pad, Ktot, row0, gather, bn_w, bn_b, bn_mean, bn_var, bn_eps, bias_src, bias_dst);
+                       cin_pad, Ktot, row0, gather, c_begin, c_count, dst_coff, bn_w, bn_b, bn_mean, bn_var, bn_eps,
+                       bias_src, bias_dst);
     return hipGetLastError();
 }
 
