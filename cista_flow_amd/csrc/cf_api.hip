@@ -86,9 +86,14 @@ struct cf_handle {
     // wrapper
     float *warpedI = nullptr, *zwarp = nullptr;
     int* flag = nullptr;
-    // flow net
-    float *encA = nullptr, *encB = nullptr, *encC = nullptr, *encD = nullptr, *encStats = nullptr, *encStats2 = nullptr;
-    double* encPartial = nullptr;
+    // flow net: one scratch set per encoder so that enet / fnet / cnet run concurrently on three streams
+    struct EncScratch {
+        float *A = nullptr, *B = nullptr, *C = nullptr, *D = nullptr, *stats = nullptr, *stats2 = nullptr;
+        double* partial = nullptr;
+    } enc[3];
+    // library-owned side streams, forked from / joined to the caller's stream with events
+    hipStream_t aux[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     float *fmap1 = nullptr, *emap = nullptr, *fcat = nullptr, *pfmap2 = nullptr, *net = nullptr, *inp = nullptr;
     float* corr[4] = {nullptr, nullptr, nullptr, nullptr};
     int clh[4] = {0, 0, 0, 0}, clw[4] = {0, 0, 0, 0};
@@ -164,13 +169,15 @@ static void setup_buffers(cf_handle* H_) {
     s.zwarp = a.f(B * hw * 2 * bc);
     if (s.cfg.mode == CF_MODE_EIFLOW) {
         const size_t P1 = (size_t)s.H1 * s.W1, N = s.N;
-        s.encA = a.f(B * P1 * 64);
-        s.encB = a.f(B * P1 * 64);
-        s.encC = a.f(B * P1 * 64);
-        s.encD = a.f(B * P1 * 64);
-        s.encStats = a.f(B * 256 * 2);
-        s.encStats2 = a.f(B * 256 * 2);
-        s.encPartial = reinterpret_cast<double*>(a.raw(sizeof(double) * (size_t)inorm_partial_doubles(s.B, (int)P1, 128)));
+        for (int e = 0; e < 3; ++e) {
+            s.enc[e].A = a.f(B * P1 * 64);
+            s.enc[e].B = a.f(B * P1 * 64);
+            s.enc[e].C = a.f(B * P1 * 64);
+            s.enc[e].D = a.f(B * P1 * 64);
+            s.enc[e].stats = a.f(B * 256 * 2);
+            s.enc[e].stats2 = a.f(B * 256 * 2);
+            s.enc[e].partial = reinterpret_cast<double*>(a.raw(sizeof(double) * (size_t)inorm_partial_doubles(s.B, (int)P1, 128)));
+        }
         s.fmap1 = a.f(B * N * 256);
         s.emap = a.f(B * N * 256);
         s.fcat = a.f(B * N * 384);
@@ -514,6 +521,18 @@ extern "C" int cf_create(cf_handle** out, const cf_config* cfg) {
         g_create_error = "cf_create: workspace hipMemset failed";
         return CF_ERR_HIP;
     }
+    bool ok = true;
+    for (int i = 0; i < 2; ++i) {
+        ok = ok && hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming) == hipSuccess;
+    }
+    ok = ok && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        (void)hipFree(h->arena_mem);
+        delete h;
+        g_create_error = "cf_create: stream/event creation failed";
+        return CF_ERR_HIP;
+    }
     h->arena.base = static_cast<char*>(h->arena_mem);
     h->arena.cap = bytes;
     h->arena.measure = false;
@@ -527,6 +546,11 @@ extern "C" void cf_destroy(cf_handle* h) {
     (void)hipSetDevice(h->cfg.device);
     for (void* p : h->owned) (void)hipFree(p);
     if (h->arena_mem) (void)hipFree(h->arena_mem);
+    for (int i = 0; i < 2; ++i) {
+        if (h->aux[i]) { (void)hipStreamSynchronize(h->aux[i]); (void)hipStreamDestroy(h->aux[i]); }
+        if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
+    }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (auto& r : h->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : h->prof_pool) (void)hipEventDestroy(e);
     delete h;
@@ -691,11 +715,12 @@ extern "C" int cf_cista_forward(cf_handle* h, const float* ev, const float* img,
 // ---------------------------------------------------------------------------------------------
 // in: planar [B][Cin][H][W] (un-padded); out: NHWC [B][N][256] (or tanh|relu split when out2 != null)
 static int encoder_forward(cf_handle* h, const std::string& pre, bool bn, const float* in, int Cin, float scale,
-                           float shift, float* out, float* out2, hipStream_t st) {
+                           float shift, float* out, float* out2, int scratch, hipStream_t st) {
     const int B = h->B;
     const float eps = 1e-5f;
     int Hc = h->H1, Wc = h->W1;   // current resolution
-    float *A = h->encA, *Bf = h->encB, *Cf = h->encC, *Df = h->encD;
+    cf_handle::EncScratch& sc = h->enc[scratch];
+    float *A = sc.A, *Bf = sc.B, *Cf = sc.C, *Df = sc.D;
     auto K = [&](const std::string& k) -> const PackedConv& { return h->conv[pre + "." + k]; };
     // conv1 7x7 s2 (+norm1 + relu)
     {
@@ -703,8 +728,8 @@ static int encoder_forward(cf_handle* h, const std::string& pre, bool bn, const 
                                    bn ? A : Bf, 64, (long)Hc * Wc * 64, bn ? EPI_RELU : EPI_NONE);
         CF_HIP(h, run_conv(h, p, B, st));
         if (!bn) {
-            CF_HIP(h, launch_inorm_stats(Bf, 64, (long)Hc * Wc * 64, B, Hc * Wc, 64, eps, h->encPartial, h->encStats, st));
-            CF_HIP(h, launch_inorm_apply(Bf, 64, (long)Hc * Wc * 64, h->encStats, nullptr, 0, 0, nullptr, A, 64,
+            CF_HIP(h, launch_inorm_stats(Bf, 64, (long)Hc * Wc * 64, B, Hc * Wc, 64, eps, sc.partial, sc.stats, st));
+            CF_HIP(h, launch_inorm_apply(Bf, 64, (long)Hc * Wc * 64, sc.stats, nullptr, 0, 0, nullptr, A, 64,
                                          (long)Hc * Wc * 64, B, Hc * Wc, 64, st));
         }
     }
@@ -737,11 +762,11 @@ static int encoder_forward(cf_handle* h, const std::string& pre, bool bn, const 
             } else {
                 ConvParams c1 = nhwc_conv(K(b + ".conv1"), {{A, Cx, Cx, ibs}}, Hc, Wc, Ho, Wo, stride, 1, 1, 0, Bf, Cd, obs, EPI_NONE);
                 CF_HIP(h, run_conv(h, c1, B, st));
-                CF_HIP(h, launch_inorm_stats(Bf, Cd, obs, B, Ho * Wo, Cd, eps, h->encPartial, h->encStats, st));
-                CF_HIP(h, launch_inorm_apply(Bf, Cd, obs, h->encStats, nullptr, 0, 0, nullptr, Cf, Cd, obs, B, Ho * Wo, Cd, st));
+                CF_HIP(h, launch_inorm_stats(Bf, Cd, obs, B, Ho * Wo, Cd, eps, sc.partial, sc.stats, st));
+                CF_HIP(h, launch_inorm_apply(Bf, Cd, obs, sc.stats, nullptr, 0, 0, nullptr, Cf, Cd, obs, B, Ho * Wo, Cd, st));
                 ConvParams c2 = nhwc_conv(K(b + ".conv2"), {{Cf, Cd, Cd, obs}}, Ho, Wo, Ho, Wo, 1, 1, 1, 0, Bf, Cd, obs, EPI_NONE);
                 CF_HIP(h, run_conv(h, c2, B, st));
-                CF_HIP(h, launch_inorm_stats(Bf, Cd, obs, B, Ho * Wo, Cd, eps, h->encPartial, h->encStats, st));
+                CF_HIP(h, launch_inorm_stats(Bf, Cd, obs, B, Ho * Wo, Cd, eps, sc.partial, sc.stats, st));
                 const float* res = A;
                 int res_ld = Cx;
                 long res_bs = ibs;
@@ -749,10 +774,10 @@ static int encoder_forward(cf_handle* h, const std::string& pre, bool bn, const 
                 if (stride != 1) {
                     ConvParams ds = nhwc_conv(K(b + ".downsample.0"), {{A, Cx, Cx, ibs}}, Hc, Wc, Ho, Wo, stride, 0, 0, 0, Cf, Cd, obs, EPI_NONE);
                     CF_HIP(h, run_conv(h, ds, B, st));
-                    CF_HIP(h, launch_inorm_stats(Cf, Cd, obs, B, Ho * Wo, Cd, eps, h->encPartial, h->encStats2, st));
-                    res = Cf; res_ld = Cd; res_bs = obs; res_stats = h->encStats2;
+                    CF_HIP(h, launch_inorm_stats(Cf, Cd, obs, B, Ho * Wo, Cd, eps, sc.partial, sc.stats2, st));
+                    res = Cf; res_ld = Cd; res_bs = obs; res_stats = sc.stats2;
                 }
-                CF_HIP(h, launch_inorm_apply(Bf, Cd, obs, h->encStats, res, res_ld, res_bs, res_stats, Df, Cd, obs, B, Ho * Wo, Cd, st));
+                CF_HIP(h, launch_inorm_apply(Bf, Cd, obs, sc.stats, res, res_ld, res_bs, res_stats, Df, Cd, obs, B, Ho * Wo, Cd, st));
                 std::swap(A, Df);
             }
             Hc = Ho; Wc = Wo; Cx = Cd;
@@ -781,16 +806,39 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
     const int B = h->B, h8 = h->h8, w8 = h->w8;
     const long N = h->N;
     int rc;
-    // encoders: emap = enet(pad(ev)); fmap1 = fnet(pad(2*I-1)); cnet(pad(2*I-1)) -> net, inp
-    if ((rc = encoder_forward(h, "event_flownet.enet", false, ev, h->cfg.num_bins, 1.f, 0.f, h->emap, nullptr, st))) return rc;
-    if ((rc = encoder_forward(h, "event_flownet.fnet", false, img, 1, 2.f, -1.f, h->fmap1, nullptr, st))) return rc;
-    if ((rc = encoder_forward(h, "event_flownet.cnet", true, img, 1, 2.f, -1.f, h->net, h->inp, st))) return rc;
+    // encoders: emap = enet(pad(ev)); fmap1 = fnet(pad(2*I-1)); cnet(pad(2*I-1)) -> net, inp.
+    // The three encoders are independent and individually too small to fill 256 CUs at 1/4 and 1/8
+    // resolution, so they run concurrently: enet on the caller's stream, fnet / cnet on the side streams.
+    CF_HIP(h, hipEventRecord(h->ev_fork, st));
+    CF_HIP(h, hipStreamWaitEvent(h->aux[0], h->ev_fork, 0));
+    CF_HIP(h, hipStreamWaitEvent(h->aux[1], h->ev_fork, 0));
+    if ((rc = encoder_forward(h, "event_flownet.enet", false, ev, h->cfg.num_bins, 1.f, 0.f, h->emap, nullptr, 0, st))) return rc;
+    if ((rc = encoder_forward(h, "event_flownet.fnet", false, img, 1, 2.f, -1.f, h->fmap1, nullptr, 1, h->aux[0]))) return rc;
+    if ((rc = encoder_forward(h, "event_flownet.cnet", true, img, 1, 2.f, -1.f, h->net, h->inp, 2, h->aux[1]))) return rc;
+    // cnet-only consumers stay on its stream: iteration-invariant `inp` part of the six GRU convolutions
+    for (int pass = 0; pass < 2; ++pass) {
+        const int pT = pass == 0 ? 0 : 2, pL = pass == 0 ? 2 : 0;
+        ConvParams g = nhwc_conv(h->conv[pass == 0 ? "gru.pre1" : "gru.pre2"], {{h->inp, 128, 128, N * 128}}, h8, w8, h8, w8, 1, pT, pL, 0, h->gpre[pass], 384, N * 384, EPI_NONE);
+        CF_HIP(h, run_conv(h, g, B, h->aux[1]));
+    }
+    CF_HIP(h, hipEventRecord(h->ev_join[0], h->aux[0]));
+    CF_HIP(h, hipEventRecord(h->ev_join[1], h->aux[1]));
+    // emap-only consumers overlap with the tail of fnet / cnet (with_event_updater.py:105-106 is
+    // iteration-invariant)
+    {
+        ConvParams a = nhwc_conv(h->conv["conve1"], {{h->emap, 256, 256, N * 256}}, h8, w8, h8, w8, 1, 0, 0, 0, h->e1buf, 128, N * 128, EPI_RELU);
+        CF_HIP(h, run_conv(h, a, B, st));
+        ConvParams b = nhwc_conv(h->conv["conve2"], {{h->e1buf, 128, 128, N * 128}}, h8, w8, h8, w8, 1, 1, 1, 0, h->mcat + 192, 320, N * 320, EPI_RELU);
+        CF_HIP(h, run_conv(h, b, B, st));
+        ConvParams c = nhwc_conv(h->conv["fusion.conv2"], {{h->emap, 256, 256, N * 256}}, h8, w8, h8, w8, 1, 0, 0, 0, h->fcat + 192, 384, N * 384, EPI_RELU);
+        CF_HIP(h, run_conv(h, c, B, st));
+    }
+    CF_HIP(h, hipStreamWaitEvent(st, h->ev_join[0], 0));
+    CF_HIP(h, hipStreamWaitEvent(st, h->ev_join[1], 0));
     // EIFusion  DCEIFlow.py:39-44
     {
         ConvParams a = nhwc_conv(h->conv["fusion.conv1"], {{h->fmap1, 256, 256, N * 256}}, h8, w8, h8, w8, 1, 0, 0, 0, h->fcat, 384, N * 384, EPI_RELU);
         CF_HIP(h, run_conv(h, a, B, st));
-        ConvParams b = nhwc_conv(h->conv["fusion.conv2"], {{h->emap, 256, 256, N * 256}}, h8, w8, h8, w8, 1, 0, 0, 0, h->fcat + 192, 384, N * 384, EPI_RELU);
-        CF_HIP(h, run_conv(h, b, B, st));
         ConvParams o = nhwc_conv(h->conv["fusion.convo"], {{h->fcat, 384, 384, N * 384}}, h8, w8, h8, w8, 1, 1, 1, 0, h->pfmap2, 256, N * 256, EPI_RELU_ADD_AUX);
         set_aux0(o, h->fmap1, 256, N * 256);
         CF_HIP(h, run_conv(h, o, B, st));
@@ -810,19 +858,6 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
         for (int l = 1; l < 4; ++l)
             CF_HIP(h, launch_corr_pool(h->corr[l - 1], h->corr[l], (long)B * N, h->clh[l - 1], h->clw[l - 1], st));
     }
-    // emap branch of the motion encoder is iteration-invariant (with_event_updater.py:105-106)
-    {
-        ConvParams a = nhwc_conv(h->conv["conve1"], {{h->emap, 256, 256, N * 256}}, h8, w8, h8, w8, 1, 0, 0, 0, h->e1buf, 128, N * 128, EPI_RELU);
-        CF_HIP(h, run_conv(h, a, B, st));
-        ConvParams b = nhwc_conv(h->conv["conve2"], {{h->e1buf, 128, 128, N * 128}}, h8, w8, h8, w8, 1, 1, 1, 0, h->mcat + 192, 320, N * 320, EPI_RELU);
-        CF_HIP(h, run_conv(h, b, B, st));
-    }
-    // iteration-invariant `inp` contribution of the six GRU convolutions (z | r | q stacked per pass)
-    for (int pass = 0; pass < 2; ++pass) {
-        const int pT = pass == 0 ? 0 : 2, pL = pass == 0 ? 2 : 0;
-        ConvParams g = nhwc_conv(h->conv[pass == 0 ? "gru.pre1" : "gru.pre2"], {{h->inp, 128, 128, N * 128}}, h8, w8, h8, w8, 1, pT, pL, 0, h->gpre[pass], 384, N * 384, EPI_NONE);
-        CF_HIP(h, run_conv(h, g, B, st));
-    }
     CF_HIP(h, launch_coords_init(h->coords1, flow_init, B, h8, w8, st));
     if (flag) CF_HIP(h, hipMemsetAsync(flag, 0, sizeof(int), st));
     const int iters = h->cfg.iters;
@@ -834,15 +869,22 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
         lp.motion = h->motion; lp.mo_ld = 128; lp.mo_off = 126;
         lp.B = B; lp.h8 = h8; lp.w8 = w8; lp.radius = 4; lp.nlevels = 4;
         CF_HIP(h, launch_corr_lookup(lp, st));
-        // BasicMotionEncoder  with_event_updater.py:102-112
+        // BasicMotionEncoder  with_event_updater.py:102-112.  The flow branch (convf1 -> convf2) only needs
+        // coords1, so it runs on a side stream next to lookup -> convc1 -> convc2.
+        CF_HIP(h, hipEventRecord(h->ev_fork, st));
+        CF_HIP(h, hipStreamWaitEvent(h->aux[0], h->ev_fork, 0));
+        {
+            ConvParams f1 = gather_conv(h->conv["convf1"], h->coords1, 2, h8, w8, 0, 0, 1.f, 0.f, 1, h8, w8, 1, 3, 3, 0, h->f1buf, 128, N * 128, EPI_RELU);
+            CF_HIP(h, run_conv(h, f1, B, h->aux[0]));
+            ConvParams f2 = nhwc_conv(h->conv["convf2"], {{h->f1buf, 128, 128, N * 128}}, h8, w8, h8, w8, 1, 1, 1, 0, h->mcat + 256, 320, N * 320, EPI_RELU);
+            CF_HIP(h, run_conv(h, f2, B, h->aux[0]));
+            CF_HIP(h, hipEventRecord(h->ev_join[0], h->aux[0]));
+        }
         ConvParams c1 = nhwc_conv(h->conv["convc1"], {{h->corrfeat, cf_handle::CORR_LD, cf_handle::CORR_LD, N * cf_handle::CORR_LD}}, h8, w8, h8, w8, 1, 0, 0, 0, h->c1buf, 256, N * 256, EPI_RELU);
         CF_HIP(h, run_conv(h, c1, B, st));
         ConvParams c2 = nhwc_conv(h->conv["convc2"], {{h->c1buf, 256, 256, N * 256}}, h8, w8, h8, w8, 1, 1, 1, 0, h->mcat, 320, N * 320, EPI_RELU);
         CF_HIP(h, run_conv(h, c2, B, st));
-        ConvParams f1 = gather_conv(h->conv["convf1"], h->coords1, 2, h8, w8, 0, 0, 1.f, 0.f, 1, h8, w8, 1, 3, 3, 0, h->f1buf, 128, N * 128, EPI_RELU);
-        CF_HIP(h, run_conv(h, f1, B, st));
-        ConvParams f2 = nhwc_conv(h->conv["convf2"], {{h->f1buf, 128, 128, N * 128}}, h8, w8, h8, w8, 1, 1, 1, 0, h->mcat + 256, 320, N * 320, EPI_RELU);
-        CF_HIP(h, run_conv(h, f2, B, st));
+        CF_HIP(h, hipStreamWaitEvent(st, h->ev_join[0], 0));
         ConvParams mc = nhwc_conv(h->conv["menc.conv"], {{h->mcat, 320, 320, N * 320}}, h8, w8, h8, w8, 1, 1, 1, 0, h->motion, 128, N * 128, EPI_RELU);
         CF_HIP(h, run_conv(h, mc, B, st));
         // SepConvGRU  with_event_updater.py:52-67 ; hx = cat(h, inp, motion), inp part precomputed (gpre)
