@@ -185,53 +185,74 @@ __device__ __forceinline__ void epilogue4(const ConvParams& p, int b, int m, int
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int AMODE>
+// WK > 1: intra-workgroup split-K.  The 4 waves are arranged WAVES_M x WAVES_N x WK; one stage holds
+// 16*WK k-columns and wave (.., wk) consumes columns [16*wk, 16*wk+16).  The partial accumulators are summed
+// through LDS before the epilogue.  This keeps 4 waves busy on 32x32 / 32x64 output tiles, which is what the
+// 1/8-resolution layers (M = 768 pixels per image) need to fill 256 CUs.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int WK, int AMODE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
-    static_assert(BM % 64 == 0, "BM multiple of 64");
+    static_assert(WAVES_M * WAVES_N * WK == 4, "4 waves per workgroup");
+    static_assert(BM % 32 == 0 && BN % 32 == 0, "tiles are multiples of the 32x32 MFMA");
+    static_assert(AMODE == A_NHWC || WK == 1, "split-K tiles only for the plain NHWC read");
+    constexpr int KS = KC * WK;          // k-columns per stage
+    constexpr int QPR = KS / 4;          // 16-byte quads per row
+    constexpr int LS = KS + 4;           // LDS row stride (floats): 16-byte slot (LS/4)*r mod 16 is a permutation
+    constexpr int WMN = WAVES_M * WAVES_N;
     constexpr int TM = BM / (32 * WAVES_M);
     constexpr int TN = BN / (32 * WAVES_N);
-    constexpr int A_IT = BM / 64;
-    constexpr int B_IT = (BN * 4 + 255) / 256;
-    constexpr int STAGE = (BM + BN) * LDS_S;
+    constexpr int A_IT = (BM * QPR + 255) / 256;
+    constexpr int B_IT = (BN * QPR + 255) / 256;
+    constexpr int STAGE = (BM + BN) * LS;
     constexpr int GTAB = (AMODE == A_GATHER) ? 256 : 4;
+    constexpr int RED = (WK - 1) * WMN * TM * TN * 1024;            // split-K reduction area (floats)
+    constexpr int SMEM = (2 * STAGE > RED + WMN * 32 * EPI_S) ? 2 * STAGE : RED + WMN * 32 * EPI_S;
 
-    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
     __shared__ __attribute__((aligned(16))) int gtab[GTAB];   // A_GATHER: k -> (ky | kx<<8 | c<<16), -1 = pad
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave / WAVES_N;
-    const int wn = wave % WAVES_N;
+    const int wk = wave / WMN;
+    const int wmn = wave % WMN;
+    const int wm = wmn / WAVES_N;
+    const int wn = wmn % WAVES_N;
     const int b = blockIdx.z;
     const int m0 = blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
     const int M = p.Ho * p.Wo;
-    const int q = tid & 3;
-    const int rbase = tid >> 2;
 
-    // per-thread A rows (fixed for the whole K loop)
-    int a_oy[A_IT], a_ox[A_IT];
-    bool a_ok[A_IT];
+    // per-thread A slots (row, quad) -- fixed for the whole K loop
+    int a_oy[A_IT], a_ox[A_IT], a_row[A_IT], a_q[A_IT];
+    bool a_ok[A_IT], a_live[A_IT];
 #pragma unroll
     for (int j = 0; j < A_IT; ++j) {
-        const int m = m0 + rbase + 64 * j;
-        a_ok[j] = m < M;
+        const int slot = tid + 256 * j;
+        const int row = slot / QPR;
+        a_row[j] = row;
+        a_q[j] = slot - row * QPR;
+        a_live[j] = row < BM;
+        const int m = m0 + row;
+        a_ok[j] = a_live[j] && m < M;
         const int oy = m / p.Wo;
         a_oy[j] = oy * p.stride - p.padT;
         a_ox[j] = (m - oy * p.Wo) * p.stride - p.padL;
     }
-    // per-thread B rows
+    // per-thread B slots
     const float* b_ptr[B_IT];
-    bool b_ok[B_IT];
+    bool b_ok[B_IT], b_live[B_IT];
+    int b_row[B_IT], b_q[B_IT];
     {
         const float* wbase = p.w + (long)b * p.w_bs;
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
-            const int row = (tid + 256 * it) >> 2;
-            b_ok[it] = row < BN && (n0 + row) < p.w_rows;
-            b_ptr[it] = wbase + (long)(b_ok[it] ? (n0 + row) : 0) * p.Ktot + q * 4;
+            const int slot = tid + 256 * it;
+            const int row = slot / QPR;
+            b_row[it] = row;
+            b_q[it] = slot - row * QPR;
+            b_live[it] = row < BN;
+            b_ok[it] = b_live[it] && (n0 + row) < p.w_rows;
+            b_ptr[it] = wbase + (long)(b_ok[it] ? (n0 + row) : 0) * p.Ktot + b_q[it] * 4;
         }
     }
     if (AMODE == A_GATHER) {
@@ -253,14 +274,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int nck = p.Ktot / KC;
+    const int nck = p.Ktot / KS;
 
     // ---- chunk iterator (wave-uniform): tap (ky,kx), channel segment, channel offset inside it ----
     int it_ky = 0, it_kx = 0, it_seg = 0, it_cs = 0, it_k = 0;
     const float* seg_base = p.in[0] + (long)b * p.seg_bs[0];
     int seg_ld = p.seg_ld[0], seg_cn = p.seg_c[0];
 
-    // per-tap, per-row source pixel (element index into the NHWC plane, -1 = zero padding / out of range)
+    // per-tap, per-slot source pixel (element index into the NHWC plane, -1 = zero padding / out of range)
     int a_pix[A_IT];
     // A_UPS2X: the four bilinear taps and weights of each row
     int u_p01[A_IT], u_p10[A_IT], u_p11[A_IT];
@@ -312,10 +333,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         // ---- A ----
         if (AMODE == A_GATHER) {
             const float* src = seg_base;
-            const int4 tb = *reinterpret_cast<const int4*>(&gtab[it_k + q * 4]);
-            const int te[4] = {tb.x, tb.y, tb.z, tb.w};
 #pragma unroll
             for (int j = 0; j < A_IT; ++j) {
+                const int4 tb = *reinterpret_cast<const int4*>(&gtab[it_k + a_q[j] * 4]);
+                const int te[4] = {tb.x, tb.y, tb.z, tb.w};
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -344,23 +365,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                 a_reg[j] = v;
             }
         } else if (AMODE == A_NHWC) {
-            const float* src = seg_base + it_cs + q * 4;
+            const float* src = seg_base + it_cs;
 #pragma unroll
             for (int j = 0; j < A_IT; ++j) {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (a_pix[j] >= 0) v = *reinterpret_cast<const f32x4*>(src + (long)a_pix[j] * seg_ld);
+                if (a_pix[j] >= 0) v = *reinterpret_cast<const f32x4*>(src + (long)a_pix[j] * seg_ld + a_q[j] * 4);
                 a_reg[j] = v;
             }
         } else {
-            const float* src = seg_base + it_cs + q * 4;
+            const float* src = seg_base + it_cs;
 #pragma unroll
             for (int j = 0; j < A_IT; ++j) {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (a_pix[j] >= 0) {
-                    const f32x4 v00 = *reinterpret_cast<const f32x4*>(src + (long)a_pix[j] * seg_ld);
-                    const f32x4 v01 = *reinterpret_cast<const f32x4*>(src + (long)u_p01[j] * seg_ld);
-                    const f32x4 v10 = *reinterpret_cast<const f32x4*>(src + (long)u_p10[j] * seg_ld);
-                    const f32x4 v11 = *reinterpret_cast<const f32x4*>(src + (long)u_p11[j] * seg_ld);
+                    const int qo = a_q[j] * 4;
+                    const f32x4 v00 = *reinterpret_cast<const f32x4*>(src + (long)a_pix[j] * seg_ld + qo);
+                    const f32x4 v01 = *reinterpret_cast<const f32x4*>(src + (long)u_p01[j] * seg_ld + qo);
+                    const f32x4 v10 = *reinterpret_cast<const f32x4*>(src + (long)u_p10[j] * seg_ld + qo);
+                    const f32x4 v11 = *reinterpret_cast<const f32x4*>(src + (long)u_p11[j] * seg_ld + qo);
                     const float ly1 = u_ly1[j], lx1 = u_lx1[j];
                     const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
 #pragma unroll
@@ -371,9 +393,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             }
         }
         // ---- advance the iterator to the next chunk ----
-        it_k += KC;
+        it_k += KS;
         if (AMODE != A_GATHER) {
-            it_cs += KC;
+            it_cs += KS;
             if (it_cs >= seg_cn) {
                 it_cs = 0;
                 ++it_seg;
@@ -395,15 +417,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 
     auto store_chunk = [&](int buf) {
         float* sA = smem + buf * STAGE;
-        float* sB = sA + BM * LDS_S;
+        float* sB = sA + BM * LS;
 #pragma unroll
         for (int j = 0; j < A_IT; ++j)
-            *reinterpret_cast<f32x4*>(sA + (rbase + 64 * j) * LDS_S + q * 4) = a_reg[j];
+            if (a_live[j]) *reinterpret_cast<f32x4*>(sA + a_row[j] * LS + a_q[j] * 4) = a_reg[j];
 #pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            const int row = (tid + 256 * it) >> 2;
-            if (row < BN) *reinterpret_cast<f32x4*>(sB + row * LDS_S + q * 4) = b_reg[it];
-        }
+        for (int it = 0; it < B_IT; ++it)
+            if (b_live[it]) *reinterpret_cast<f32x4*>(sB + b_row[it] * LS + b_q[it] * 4) = b_reg[it];
     };
 
     load_chunk();
@@ -415,17 +435,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     for (int ck = 0; ck < nck; ++ck) {
         const int buf = ck & 1;
         if (ck + 1 < nck) load_chunk();
-        const float* sA = smem + buf * STAGE;
-        const float* sB = sA + BM * LDS_S;
+        const float* sA = smem + buf * STAGE + wk * KC;
+        const float* sB = smem + buf * STAGE + BM * LS + wk * KC;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             f32x4 af[TM], bf[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                af[i] = *reinterpret_cast<const f32x4*>(sA + ((wm * TM + i) * 32 + lr) * LDS_S + ks * 8 + lh * 4);
+                af[i] = *reinterpret_cast<const f32x4*>(sA + ((wm * TM + i) * 32 + lr) * LS + ks * 8 + lh * 4);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                bf[j] = *reinterpret_cast<const f32x4*>(sB + ((wn * TN + j) * 32 + lr) * LDS_S + ks * 8 + lh * 4);
+                bf[j] = *reinterpret_cast<const f32x4*>(sB + ((wn * TN + j) * 32 + lr) * LS + ks * 8 + lh * 4);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -438,11 +458,36 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         __syncthreads();
     }
 
+    // ---- split-K: fold the partial accumulators of the wk > 0 waves into the wk == 0 wave ----
+    if (WK > 1) {
+        float* red = smem;
+        if (wk > 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        red[((((wk - 1) * WMN + wmn) * TM + i) * TN + j) * 1024 + r * 64 + lane] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (wk > 0) return;
+#pragma unroll
+        for (int k = 1; k < WK; ++k)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[i][j][r] += red[((((k - 1) * WMN + wmn) * TM + i) * TN + j) * 1024 + r * 64 + lane];
+    }
+
     // ---- epilogue ----
     // C/D map of the 32x32 MFMA: col = lane&31 (cout), row = (r&3)+8*(r>>2)+4*(lane>>5).  Each
     // 32x32 sub-tile goes through a per-wave LDS patch so that a lane ends up with 4 consecutive
     // couts of one pixel: aux reads and the store are then 16-byte accesses on 128-byte rows.
-    float* sW = smem + wave * (32 * EPI_S);
+    float* sW = smem + RED + wmn * (32 * EPI_S);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -468,14 +513,28 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int WK>
 static hipError_t launch_t(const ConvParams& p, int batch, hipStream_t s) {
     const int M = p.Ho * p.Wo;
     dim3 grid((M + BM - 1) / BM, (p.cout + BN - 1) / BN, batch);
-    if (p.a_mode == A_NHWC) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, A_NHWC>), grid, dim3(256), 0, s, p);
-    else if (p.a_mode == A_UPS2X) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, A_UPS2X>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, A_GATHER>), grid, dim3(256), 0, s, p);
+    if (p.a_mode == A_NHWC) {
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, WK, A_NHWC>), grid, dim3(256), 0, s, p);
+    } else if constexpr (WK == 1) {
+        if (p.a_mode == A_UPS2X) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1, A_UPS2X>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1, A_GATHER>), grid, dim3(256), 0, s, p);
+    } else {
+        return hipErrorInvalidValue;
+    }
     return hipGetLastError();
+}
+
+// split-K tiles need every channel segment to be a whole number of stages
+static bool splitk_ok(const ConvParams& p, int wk) {
+    if (p.a_mode != A_NHWC) return false;
+    const int ks = KC * wk;
+    for (int i = 0; i < p.nseg; ++i)
+        if (p.seg_c[i] % ks) return false;
+    return true;
 }
 
 // tile ids: 1 = 128x128, 2 = 128x64, 3 = 128x96, 4 = 64x64, 5 = 64x128, 6 = 128x32
@@ -569,6 +628,8 @@ const char* conv_tile_name(int tile) {
         case 5: return "conv_igemm_kernel<64,128,2,2>";
         case 6: return "conv_igemm_kernel<128,32,4,1>";
         case 7: return "conv_smalln_kernel";
+        case 8: return "conv_igemm_kernel<32,32,1,1,k4>";
+        case 9: return "conv_igemm_kernel<32,64,1,2,k2>";
         default: return "?";
     }
 }
@@ -611,28 +672,39 @@ hipError_t launch_conv(const ConvParams& p, int batch, hipStream_t s, int tile, 
         return launch_smalln(p, batch, s);
     }
     if (tile == 0) {
-        const int M = p.Ho * p.Wo;
-        int bn;
-        if (p.cout <= 32) bn = 32;
-        else if (p.cout <= 64) bn = 64;
-        else if ((p.cout % 96) == 0 && (p.cout % 128) != 0) bn = 96;
-        else bn = 128;
-        const long wg128 = (long)((M + 127) / 128) * ((p.cout + bn - 1) / bn) * batch;
-        // measured on MI355X (tools/conv_bench.py): below ~512 workgroups the 64x64 tile wins even when it
-        // pads cout (96 -> 128), because the 128-row tiles leave most CUs idle
-        if (bn == 32) tile = 6;
-        else if (bn == 96) tile = (wg128 >= 512) ? 3 : 4;
-        else if (bn == 64) tile = (wg128 >= 512) ? 2 : 4;
-        else tile = (wg128 >= 512) ? 1 : ((long)((M + 63) / 64) * ((p.cout + 127) / 128) * batch >= 512 ? 5 : 4);
+        // Pick the largest tile that still yields >= ~2 workgroups per CU (measured with tools/conv_bench.py on
+        // MI355X): big tiles reuse operands best, but a launch with fewer than ~512 workgroups leaves CUs idle,
+        // so small-M layers step down to 64x64 and then to the intra-workgroup split-K tiles (32x64, 32x32).
+        const long M = (long)p.Ho * p.Wo;
+        auto wgs = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((p.cout + bn - 1) / bn) * batch; };
+        const long FILL = 512;
+        if (p.cout <= 32) {
+            tile = (wgs(128, 32) >= FILL || !splitk_ok(p, 4)) ? 6 : 8;
+        } else if (p.cout <= 64) {
+            if (wgs(128, 64) >= FILL) tile = 2;
+            else if (wgs(64, 64) >= FILL) tile = 4;
+            else if (splitk_ok(p, 2) && wgs(32, 64) >= FILL) tile = 9;
+            else tile = splitk_ok(p, 4) ? 8 : 4;
+        } else {
+            const bool n96 = (p.cout % 96) == 0 && (p.cout % 128) != 0;
+            if (n96 && wgs(128, 96) >= FILL) tile = 3;
+            else if (!n96 && wgs(128, 128) >= FILL) tile = 1;
+            else if (!n96 && wgs(64, 128) >= FILL) tile = 5;
+            else if (wgs(64, 64) >= FILL) tile = 4;
+            else if (splitk_ok(p, 2) && wgs(32, 64) >= FILL) tile = 9;
+            else tile = splitk_ok(p, 4) ? 8 : (splitk_ok(p, 2) ? 9 : 4);
+        }
     }
     if (tile_used) *tile_used = tile;
     switch (tile) {
-        case 1: return launch_t<128, 128, 2, 2>(p, batch, s);
-        case 2: return launch_t<128, 64, 2, 2>(p, batch, s);
-        case 3: return launch_t<128, 96, 4, 1>(p, batch, s);
-        case 4: return launch_t<64, 64, 2, 2>(p, batch, s);
-        case 5: return launch_t<64, 128, 2, 2>(p, batch, s);
-        case 6: return launch_t<128, 32, 4, 1>(p, batch, s);
+        case 1: return launch_t<128, 128, 2, 2, 1>(p, batch, s);
+        case 2: return launch_t<128, 64, 2, 2, 1>(p, batch, s);
+        case 3: return launch_t<128, 96, 4, 1, 1>(p, batch, s);
+        case 4: return launch_t<64, 64, 2, 2, 1>(p, batch, s);
+        case 5: return launch_t<64, 128, 2, 2, 1>(p, batch, s);
+        case 6: return launch_t<128, 32, 4, 1, 1>(p, batch, s);
+        case 8: return splitk_ok(p, 4) ? launch_t<32, 32, 1, 1, 4>(p, batch, s) : hipErrorInvalidValue;
+        case 9: return splitk_ok(p, 2) ? launch_t<32, 64, 1, 2, 2>(p, batch, s) : hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }
 }

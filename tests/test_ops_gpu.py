@@ -79,6 +79,12 @@ CONV_CASES = [
     (256, 2, 3, 3, 1, 1, 1, 0, 7),     # ... and through the VALU small-N kernel explicitly
     (64, 1, 3, 3, 1, 1, 1, 1, 7),
     (128, 2, 3, 3, 1, 1, 1, 0, 7),
+    (128, 128, 3, 3, 1, 1, 1, 0, 8),   # intra-workgroup split-K tiles (32x32xK4, 32x64xK2)
+    (64, 96, 3, 3, 1, 1, 1, 1, 8),
+    (256, 126, 1, 5, 1, 0, 2, 0, 8),
+    (128, 256, 3, 3, 1, 1, 1, 0, 9),
+    (96, 96, 3, 3, 2, 1, 1, 0, 9),
+    (384, 128, 5, 1, 1, 2, 0, 0, 9),
 ]
 
 
