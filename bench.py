@@ -96,6 +96,7 @@ def main():
 
     import weights_util as wu
     from cista_flow_amd.e2v.e2v_model import DCEIFlowCistaNet
+    from cista_flow_amd.parallel import collate_frames
     B, H, W = a.batch, a.height, a.width
     model = DCEIFlowCistaNet(model_args(H, W)).eval()
     wu.fill_module(model, 1234)
@@ -103,7 +104,6 @@ def main():
     model.event_flownet.return_flow_preds = True      # like the reference: every iteration's up-flow is produced
     R = 8
     evs = [wu.synth_events(B, 5, H, W, 1234 + 100 * rank + i).to(dev) for i in range(R)]
-    gathered = torch.empty((world * B, 1, H, W), device=dev) if world > 1 else None
     side = torch.cuda.Stream(device=dev) if world > 1 else None
 
     state = {"prev": torch.zeros(B, 1, H, W, device=dev), "states": None, "i": 0}
@@ -117,7 +117,7 @@ def main():
             # collate the reconstructed frames of all ranks (RCCL all-gather over xGMI) off the critical path
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                dist.all_gather_into_tensor(gathered, I)
+                state["gathered"] = collate_frames(I)
         return I
 
     with torch.no_grad():

@@ -1,0 +1,81 @@
+"""N>1 path on CPU: world_size-2 gloo run of the sequence sharding + frame collation used by bench.py."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cista_flow_amd.parallel import collate_frames, shard_range   # noqa: E402
+
+
+def test_shard_range_covers_everything():
+    for n in (0, 1, 7, 8, 32, 33):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [e - s for s, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, n_seq, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    s, e = shard_range(n_seq, rank, world)
+    # a stand-in for the per-rank reconstruction: frame b is filled with its global sequence id
+    local = torch.stack([torch.full((1, 4, 6), float(i)) for i in range(s, e)]) if e > s else torch.zeros(0, 1, 4, 6)
+    out = collate_frames(local, n_seq)
+    ok = out.shape[0] == n_seq and all(float(out[i].mean()) == float(i) for i in range(n_seq))
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(n_seq, port):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_seq, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)
+
+
+def test_collate_equal_shards_gloo():
+    _run(8, 29611)
+
+
+def test_collate_ragged_shards_gloo():
+    _run(7, 29612)
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    """include/cistaflow.h <-> libcistaflow.so: every declared entry point is exported (no compute, no GPU)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "cistaflow.h")).read()
+    declared = sorted(set(re.findall(r"\b(cf_[a-z0-9_]+)\s*\(", hdr)))
+    from cista_flow_amd import lib
+    so = lib.load()
+    assert sorted(lib.SYMBOLS) == declared
+    for sym in declared:
+        assert hasattr(so, sym), sym
+
+
+def test_no_gpu_means_loud_failure():
+    """The product path must not fall back to anything when there is no GPU."""
+    import argparse
+    import pytest
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from cista_flow_amd.e2v.e2v_model import DCEIFlowCistaNet
+    a = argparse.Namespace(image_dim=[128, 128], num_bins=5, warp_mode='forward', base_channels=64, depth=5, ds=8, is_bi=False)
+    m = DCEIFlowCistaNet(a).eval()
+    with pytest.raises(RuntimeError):
+        m({"event_voxel": torch.zeros(1, 5, 128, 128), "rec_img0": torch.zeros(1, 1, 128, 128)}, None, {})
