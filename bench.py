@@ -117,6 +117,7 @@ def main():
             # collate the reconstructed frames of all ranks (RCCL all-gather over xGMI) off the critical path
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
+                I.record_stream(side)          # I was allocated on the main stream; keep it alive for the gather
                 state["gathered"] = collate_frames(I)
         return I
 
