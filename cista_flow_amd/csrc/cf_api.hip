@@ -100,6 +100,7 @@ struct cf_handle {
     float *coords1 = nullptr, *corrfeat = nullptr, *c1buf = nullptr, *mcat = nullptr, *e1buf = nullptr, *f1buf = nullptr,
           *motion = nullptr, *zbuf = nullptr, *rh = nullptr, *fh = nullptr;
     float* gpre[2] = {nullptr, nullptr};
+    float *mask1 = nullptr, *maskbuf = nullptr;   // ERAFT mask head
     static constexpr int CORR_LD = 336;   // 4*81 = 324 correlation channels padded to a multiple of 16
 
     // per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
@@ -167,7 +168,7 @@ static void setup_buffers(cf_handle* H_) {
     s.up = a.f(B * HW * bc);
     s.warpedI = a.f(B * HW);
     s.zwarp = a.f(B * hw * 2 * bc);
-    if (s.cfg.mode == CF_MODE_EIFLOW) {
+    if (s.cfg.mode == CF_MODE_EIFLOW || s.cfg.mode == CF_MODE_ERAFT) {
         const size_t P1 = (size_t)s.H1 * s.W1, N = s.N;
         for (int e = 0; e < 3; ++e) {
             s.enc[e].A = a.f(B * P1 * 64);
@@ -204,6 +205,10 @@ static void setup_buffers(cf_handle* H_) {
         s.fh = a.f(B * N * 256);
         s.gpre[0] = a.f(B * N * 384);
         s.gpre[1] = a.f(B * N * 384);
+        if (s.cfg.mode == CF_MODE_ERAFT) {
+            s.mask1 = a.f(B * N * 256);
+            s.maskbuf = a.f(B * N * 576);
+        }
     }
 }
 
@@ -416,22 +421,30 @@ extern "C" int cf_finalize_weights(cf_handle* h, void* stream) {
             return h->fail(CF_ERR_WEIGHT, "CISTA weights do not match num_bins/base_channels of the handle");
         h->has_cista = true;
     }
-    if (got_flow && h->cfg.mode == CF_MODE_EIFLOW) {
+    const bool eraft = h->cfg.mode == CF_MODE_ERAFT;
+    if (got_flow && (h->cfg.mode == CF_MODE_EIFLOW || eraft)) {
         const std::string& f = fn;
         if ((rc = pack_encoder(h, f + "fnet", "event_flownet.fnet", false, st))) return rc;
-        if ((rc = pack_encoder(h, f + "enet", "event_flownet.enet", false, st))) return rc;
+        if (!eraft && (rc = pack_encoder(h, f + "enet", "event_flownet.enet", false, st))) return rc;
         if ((rc = pack_encoder(h, f + "cnet", "event_flownet.cnet", true, st))) return rc;
         auto F = [&](const std::string& key, const std::string& name, bool gather) -> int {
             return pack_conv(h, key, f + name, gather, 0, 0, "", st);
         };
-        if ((rc = F("fusion.conv1", "fusion.conv1", false))) return rc;
-        if ((rc = F("fusion.conv2", "fusion.conv2", false))) return rc;
-        if ((rc = F("fusion.convo", "fusion.convo", false))) return rc;
+        if (!eraft) {
+            if ((rc = F("fusion.conv1", "fusion.conv1", false))) return rc;
+            if ((rc = F("fusion.conv2", "fusion.conv2", false))) return rc;
+            if ((rc = F("fusion.convo", "fusion.convo", false))) return rc;
+        } else {   // ERAFT/update.py:91-94
+            if ((rc = F("mask.0", "update_block.mask.0", false))) return rc;
+            if ((rc = F("mask.2", "update_block.mask.2", false))) return rc;
+        }
         const std::string e = "update_block.encoder.";
         if ((rc = F("convc1", e + "convc1", false))) return rc;
         if ((rc = F("convc2", e + "convc2", false))) return rc;
-        if ((rc = F("conve1", e + "conve1", false))) return rc;
-        if ((rc = F("conve2", e + "conve2", false))) return rc;
+        if (!eraft) {
+            if ((rc = F("conve1", e + "conve1", false))) return rc;
+            if ((rc = F("conve2", e + "conve2", false))) return rc;
+        }
         if ((rc = F("convf1", e + "convf1", true))) return rc;
         if ((rc = F("convf2", e + "convf2", false))) return rc;
         if ((rc = F("menc.conv", e + "conv", false))) return rc;
@@ -454,7 +467,9 @@ extern "C" int cf_finalize_weights(cf_handle* h, void* stream) {
         if ((rc = F("fh.conv1", "update_block.flow_head.conv1", false))) return rc;
         if ((rc = F("fh.conv2", "update_block.flow_head.conv2", false))) return rc;
         if (h->conv["convc1"].cin_pad != cf_handle::CORR_LD) return h->fail(CF_ERR_WEIGHT, "convc1 expects 324 input channels");
-        if (h->conv["event_flownet.enet.conv1"].cin != h->cfg.num_bins) return h->fail(CF_ERR_WEIGHT, "enet.conv1 does not match num_bins");
+        if (!eraft && h->conv["event_flownet.enet.conv1"].cin != h->cfg.num_bins) return h->fail(CF_ERR_WEIGHT, "enet.conv1 does not match num_bins");
+        if (eraft && (h->conv["event_flownet.fnet.conv1"].cin != h->cfg.num_bins || h->conv["menc.conv"].cin != 256))
+            return h->fail(CF_ERR_WEIGHT, "ERAFT weights do not match the handle");
         h->has_flow = true;
     }
     // the announced pointers may die after this call: drain the packing kernels
@@ -482,11 +497,11 @@ extern "C" int cf_create(cf_handle** out, const cf_config* cfg) {
     if (cfg->num_bins != 5 && cfg->num_bins < 1) return bad("cf_create: bad num_bins");
     if (cfg->base_channels < 32 || (cfg->base_channels % 32) != 0) return bad("cf_create: base_channels must be a multiple of 32");
     if (cfg->depth < 1) return bad("cf_create: bad depth");
-    if (cfg->mode != CF_MODE_CISTA && cfg->mode != CF_MODE_EIFLOW) {
-        g_create_error = "cf_create: mode not built yet (eraft / idnet)";
+    if (cfg->mode != CF_MODE_CISTA && cfg->mode != CF_MODE_EIFLOW && cfg->mode != CF_MODE_ERAFT) {
+        g_create_error = "cf_create: mode not built yet (idnet)";
         return CF_ERR_UNSUPPORTED;
     }
-    if (cfg->mode == CF_MODE_EIFLOW && cfg->iters < 1) return bad("cf_create: bad iters");
+    if ((cfg->mode == CF_MODE_EIFLOW || cfg->mode == CF_MODE_ERAFT) && cfg->iters < 1) return bad("cf_create: bad iters");
     cf_handle* h = new cf_handle();
     h->cfg = *cfg;
     h->B = cfg->batch; h->H = cfg->height; h->W = cfg->width; h->h = cfg->height / 2; h->w = cfg->width / 2;
@@ -497,7 +512,7 @@ extern "C" int cf_create(cf_handle** out, const cf_config* cfg) {
     h->Hp = h->H + h->padH; h->Wp = h->W + h->padW;
     h->H1 = h->Hp / 2; h->W1 = h->Wp / 2; h->H2 = h->Hp / 4; h->W2 = h->Wp / 4; h->h8 = h->Hp / 8; h->w8 = h->Wp / 8;
     h->N = h->h8 * h->w8;
-    if (cfg->mode == CF_MODE_EIFLOW && (h->h8 < 16 || h->w8 < 16)) {
+    if ((cfg->mode == CF_MODE_EIFLOW || cfg->mode == CF_MODE_ERAFT) && (h->h8 < 16 || h->w8 < 16)) {
         delete h;
         return bad("cf_create: padded image must be >= 128x128 (4th correlation pyramid level >= 2x2)");
     }
@@ -801,10 +816,17 @@ static int encoder_forward(cf_handle* h, const std::string& pre, bool bn, const 
 // ---------------------------------------------------------------------------------------------
 // DCEIFlow.forward  DCEIFlow.py:143-227 (image2 / reversed voxel branches are training-only)
 // ---------------------------------------------------------------------------------------------
+// ERAFT.forward  ERAFT/eraft.py:114-178 shares this graph: ev = image1 (old voxel grid), img = image2 (new voxel
+// grid); fnet runs on both (instance norm is per sample, so the reference's batch concat equals two runs),
+// cnet on image2, no fusion, no emap branch, 12 iterations, learned convex up-sampling.
 static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const float* flow_init, float* flow_final,
                           float* flow_low, float* flow_preds, int* flag, hipStream_t st) {
     const int B = h->B, h8 = h->h8, w8 = h->w8;
     const long N = h->N;
+    const bool eraft = h->cfg.mode == CF_MODE_ERAFT;
+    const int MC = eraft ? 256 : 320;        // motion-encoder concat width: cor(192) [ema(64)] flo(64)
+    const int FLO = eraft ? 192 : 256;       // channel offset of the flow branch inside it
+    const int bins = h->cfg.num_bins;
     int rc;
     // encoders: emap = enet(pad(ev)); fmap1 = fnet(pad(2*I-1)); cnet(pad(2*I-1)) -> net, inp.
     // The three encoders are independent and individually too small to fill 256 CUs at 1/4 and 1/8
@@ -812,9 +834,15 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
     CF_HIP(h, hipEventRecord(h->ev_fork, st));
     CF_HIP(h, hipStreamWaitEvent(h->aux[0], h->ev_fork, 0));
     CF_HIP(h, hipStreamWaitEvent(h->aux[1], h->ev_fork, 0));
-    if ((rc = encoder_forward(h, "event_flownet.enet", false, ev, h->cfg.num_bins, 1.f, 0.f, h->emap, nullptr, 0, st))) return rc;
-    if ((rc = encoder_forward(h, "event_flownet.fnet", false, img, 1, 2.f, -1.f, h->fmap1, nullptr, 1, h->aux[0]))) return rc;
-    if ((rc = encoder_forward(h, "event_flownet.cnet", true, img, 1, 2.f, -1.f, h->net, h->inp, 2, h->aux[1]))) return rc;
+    if (!eraft) {
+        if ((rc = encoder_forward(h, "event_flownet.enet", false, ev, bins, 1.f, 0.f, h->emap, nullptr, 0, st))) return rc;
+        if ((rc = encoder_forward(h, "event_flownet.fnet", false, img, 1, 2.f, -1.f, h->fmap1, nullptr, 1, h->aux[0]))) return rc;
+        if ((rc = encoder_forward(h, "event_flownet.cnet", true, img, 1, 2.f, -1.f, h->net, h->inp, 2, h->aux[1]))) return rc;
+    } else {
+        if ((rc = encoder_forward(h, "event_flownet.fnet", false, ev, bins, 1.f, 0.f, h->fmap1, nullptr, 0, st))) return rc;
+        if ((rc = encoder_forward(h, "event_flownet.fnet", false, img, bins, 1.f, 0.f, h->pfmap2, nullptr, 1, h->aux[0]))) return rc;
+        if ((rc = encoder_forward(h, "event_flownet.cnet", true, img, bins, 1.f, 0.f, h->net, h->inp, 2, h->aux[1]))) return rc;
+    }
     // cnet-only consumers stay on its stream: iteration-invariant `inp` part of the six GRU convolutions
     for (int pass = 0; pass < 2; ++pass) {
         const int pT = pass == 0 ? 0 : 2, pL = pass == 0 ? 2 : 0;
@@ -825,7 +853,7 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
     CF_HIP(h, hipEventRecord(h->ev_join[1], h->aux[1]));
     // emap-only consumers overlap with the tail of fnet / cnet (with_event_updater.py:105-106 is
     // iteration-invariant)
-    {
+    if (!eraft) {
         ConvParams a = nhwc_conv(h->conv["conve1"], {{h->emap, 256, 256, N * 256}}, h8, w8, h8, w8, 1, 0, 0, 0, h->e1buf, 128, N * 128, EPI_RELU);
         CF_HIP(h, run_conv(h, a, B, st));
         ConvParams b = nhwc_conv(h->conv["conve2"], {{h->e1buf, 128, 128, N * 128}}, h8, w8, h8, w8, 1, 1, 1, 0, h->mcat + 192, 320, N * 320, EPI_RELU);
@@ -836,7 +864,7 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
     CF_HIP(h, hipStreamWaitEvent(st, h->ev_join[0], 0));
     CF_HIP(h, hipStreamWaitEvent(st, h->ev_join[1], 0));
     // EIFusion  DCEIFlow.py:39-44
-    {
+    if (!eraft) {
         ConvParams a = nhwc_conv(h->conv["fusion.conv1"], {{h->fmap1, 256, 256, N * 256}}, h8, w8, h8, w8, 1, 0, 0, 0, h->fcat, 384, N * 384, EPI_RELU);
         CF_HIP(h, run_conv(h, a, B, st));
         ConvParams o = nhwc_conv(h->conv["fusion.convo"], {{h->fcat, 384, 384, N * 384}}, h8, w8, h8, w8, 1, 1, 1, 0, h->pfmap2, 256, N * 256, EPI_RELU_ADD_AUX);
@@ -876,16 +904,16 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
         {
             ConvParams f1 = gather_conv(h->conv["convf1"], h->coords1, 2, h8, w8, 0, 0, 1.f, 0.f, 1, h8, w8, 1, 3, 3, 0, h->f1buf, 128, N * 128, EPI_RELU);
             CF_HIP(h, run_conv(h, f1, B, h->aux[0]));
-            ConvParams f2 = nhwc_conv(h->conv["convf2"], {{h->f1buf, 128, 128, N * 128}}, h8, w8, h8, w8, 1, 1, 1, 0, h->mcat + 256, 320, N * 320, EPI_RELU);
+            ConvParams f2 = nhwc_conv(h->conv["convf2"], {{h->f1buf, 128, 128, N * 128}}, h8, w8, h8, w8, 1, 1, 1, 0, h->mcat + FLO, MC, N * MC, EPI_RELU);
             CF_HIP(h, run_conv(h, f2, B, h->aux[0]));
             CF_HIP(h, hipEventRecord(h->ev_join[0], h->aux[0]));
         }
         ConvParams c1 = nhwc_conv(h->conv["convc1"], {{h->corrfeat, cf_handle::CORR_LD, cf_handle::CORR_LD, N * cf_handle::CORR_LD}}, h8, w8, h8, w8, 1, 0, 0, 0, h->c1buf, 256, N * 256, EPI_RELU);
         CF_HIP(h, run_conv(h, c1, B, st));
-        ConvParams c2 = nhwc_conv(h->conv["convc2"], {{h->c1buf, 256, 256, N * 256}}, h8, w8, h8, w8, 1, 1, 1, 0, h->mcat, 320, N * 320, EPI_RELU);
+        ConvParams c2 = nhwc_conv(h->conv["convc2"], {{h->c1buf, 256, 256, N * 256}}, h8, w8, h8, w8, 1, 1, 1, 0, h->mcat, MC, N * MC, EPI_RELU);
         CF_HIP(h, run_conv(h, c2, B, st));
         CF_HIP(h, hipStreamWaitEvent(st, h->ev_join[0], 0));
-        ConvParams mc = nhwc_conv(h->conv["menc.conv"], {{h->mcat, 320, 320, N * 320}}, h8, w8, h8, w8, 1, 1, 1, 0, h->motion, 128, N * 128, EPI_RELU);
+        ConvParams mc = nhwc_conv(h->conv["menc.conv"], {{h->mcat, MC, MC, N * MC}}, h8, w8, h8, w8, 1, 1, 1, 0, h->motion, 128, N * 128, EPI_RELU);
         CF_HIP(h, run_conv(h, mc, B, st));
         // SepConvGRU  with_event_updater.py:52-67 ; hx = cat(h, inp, motion), inp part precomputed (gpre)
         for (int pass = 0; pass < 2; ++pass) {
@@ -914,12 +942,24 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
         h2.out_cs = (int)N;
         set_aux0(h2, h->coords1, 1, 2 * N, (int)N);
         CF_HIP(h, run_conv(h, h2, B, st));
-        // upflow8 + unpad   DCEIFlow.py:222-227
         const bool last = it == iters - 1;
         float* up = flow_preds ? flow_preds + (long)it * B * 2 * h->Hp * h->Wp : nullptr;
-        if (last || up)
-            CF_HIP(h, launch_upflow(h->coords1, B, h8, w8, 8, up, last ? flow_final : nullptr, h->H, h->W, h->padH, h->padW,
-                                    last ? flag : nullptr, st));
+        if (!eraft) {
+            // upflow8 + unpad   DCEIFlow.py:222-227
+            if (last || up)
+                CF_HIP(h, launch_upflow(h->coords1, B, h8, w8, 8, up, last ? flow_final : nullptr, h->H, h->W, h->padH, h->padW,
+                                        last ? flag : nullptr, st));
+        } else if (last || up) {
+            // mask = .25 * mask(net) (update.py:105) + learned convex up-sampling (eraft.py:77-88).  The reference
+            // evaluates this on all 12 iterations; only iterations whose up-flow is requested are computed here.
+            ConvParams m0 = nhwc_conv(h->conv["mask.0"], {{h->net, 128, 128, N * 128}}, h8, w8, h8, w8, 1, 1, 1, 0, h->mask1, 256, N * 256, EPI_RELU);
+            CF_HIP(h, run_conv(h, m0, B, st));
+            ConvParams m2 = nhwc_conv(h->conv["mask.2"], {{h->mask1, 256, 256, N * 256}}, h8, w8, h8, w8, 1, 0, 0, 0, h->maskbuf, 576, N * 576, EPI_BIAS_SCALE);
+            m2.scale = 0.25f;
+            CF_HIP(h, run_conv(h, m2, B, st));
+            CF_HIP(h, launch_convex_upsample(h->coords1, 0, h->maskbuf, 576, B, h8, w8, up, last ? flow_final : nullptr, h->H,
+                                             h->W, h->padH, h->padW, last ? flag : nullptr, st));
+        }
     }
     if (flow_low) {
         // flow_init of the returned dict = coords1 - coords0 at 1/8 resolution (DCEIFlow.py:297)
@@ -932,7 +972,7 @@ extern "C" int cf_flow_forward(cf_handle* h, const float* in0, const float* in1,
                                float* flow_low, float* flow_preds, void* stream) {
     if (!h) return CF_ERR_ARG;
     if (!h->finalized || !h->has_flow) return h->fail(CF_ERR_STATE, "cf_flow_forward: flow-net weights not finalised");
-    if (h->cfg.mode != CF_MODE_EIFLOW) return h->fail(CF_ERR_UNSUPPORTED, "cf_flow_forward: handle has no flow network");
+    if (h->cfg.mode != CF_MODE_EIFLOW && h->cfg.mode != CF_MODE_ERAFT) return h->fail(CF_ERR_UNSUPPORTED, "cf_flow_forward: handle has no flow network");
     if (!in0 || !in1 || !flow_final) return h->fail(CF_ERR_ARG, "cf_flow_forward: null pointer");
     CF_HIP(h, hipSetDevice(h->cfg.device));
     return eiflow_forward(h, in0, in1, flow_init, flow_final, flow_low, flow_preds, h->flag, static_cast<hipStream_t>(stream));
@@ -947,7 +987,7 @@ extern "C" int cf_step(cf_handle* h, const float* in0, const float* in1, const f
                        float* z_warped_out, float* c_out, float* z_out, float* h_out, float* cc_out, void* stream) {
     if (!h) return CF_ERR_ARG;
     if (!h->finalized || !h->has_cista || !h->has_flow) return h->fail(CF_ERR_STATE, "cf_step: weights not finalised");
-    if (h->cfg.mode != CF_MODE_EIFLOW) return h->fail(CF_ERR_UNSUPPORTED, "cf_step: mode not built yet");
+    if (h->cfg.mode != CF_MODE_EIFLOW && h->cfg.mode != CF_MODE_ERAFT) return h->fail(CF_ERR_UNSUPPORTED, "cf_step: mode not built yet");
     if (!in0 || !in1 || !rec_img0 || !I_out || !flow_final || !c_out || !z_out || !h_out || !cc_out)
         return h->fail(CF_ERR_ARG, "cf_step: null pointer");
     if ((h_prev == nullptr) != (cc_prev == nullptr)) return h->fail(CF_ERR_ARG, "cf_step: h_prev/cc_prev must come together");
@@ -972,7 +1012,9 @@ extern "C" int cf_step(cf_handle* h, const float* in0, const float* in1, const f
         CF_HIP(h, launch_warp(z_prev, c2, hw * c2, flow, h->H, h->W, zw, c2, hw * c2, h->B, c2, h->h, h->w, bwd, h->flag, st));
         zin = zw;
     }
-    return cista_forward(h, in0, h->warpedI, c_prev, zin, h_prev, cc_prev, I_out, c_out, z_out, h_out, cc_out, st);
+    // CISTA consumes the current voxel grid: in0 for eiflow, in1 (= image2) for eraft (e2v_model.py:194,246)
+    const float* ev_now = h->cfg.mode == CF_MODE_ERAFT ? in1 : in0;
+    return cista_forward(h, ev_now, h->warpedI, c_prev, zin, h_prev, cc_prev, I_out, c_out, z_out, h_out, cc_out, st);
 }
 
 // ---------------------------------------------------------------------------------------------

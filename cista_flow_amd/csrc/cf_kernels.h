@@ -38,6 +38,7 @@ enum Epi {
     EPI_SCALE = 12,          // out = acc * scale   (no bias)          (all-pairs correlation)
     EPI_LSTM_ACT = 13,       // n < split: sigmoid ; else tanh         (ConvLSTM gate pre-activation)
     EPI_ADD_AUX = 14,        // out = v + aux0                         (coords1 += delta_flow)
+    EPI_BIAS_SCALE = 15,     // out = (acc + bias) * scale             (ERAFT: .25 * mask(net))
 };
 
 struct ConvParams {
@@ -149,6 +150,14 @@ hipError_t launch_coords_init(float* coords1, const float* flow_init, int B, int
 // flag (nullable) |= any(flow_final != 0)
 hipError_t launch_upflow(const float* coords1, int B, int h8, int w8, int ds, float* flow_up,
                          float* flow_final, int H, int W, int padH, int padW, int* flag, hipStream_t s);
+
+// learned convex x8 up-sampling (ERAFT/eraft.py:77-88, idn/idedeq.py:48-61): softmax over the 9 neighbours of
+// mask [B][N][576] (channel k*64 + i*8 + j) applied to unfold(8 * flow, 3x3, pad 1); flow = coords1 - coords0
+// when `coords_is_flow == 0`, else `coords1` already holds the flow.  Writes the padded flow_up (nullable) and
+// the un-padded flow_final (nullable), raises `flag` on any non-zero flow_final value.
+hipError_t launch_convex_upsample(const float* coords1, int coords_is_flow, const float* mask, int mask_ld, int B,
+                                  int h8, int w8, float* flow_up, float* flow_final, int H, int W, int padH,
+                                  int padW, int* flag, hipStream_t s);
 
 // layout helpers for the Python boundary / tests
 hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int dst_ld, int B, int C, int HW, hipStream_t s);

@@ -163,6 +163,10 @@ __device__ __forceinline__ void epilogue4(const ConvParams& p, int b, int m, int
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = acc[e] * p.scale;
             break;
+        case EPI_BIAS_SCALE:
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = v[e] * p.scale;
+            break;
         case EPI_LSTM_ACT:
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (n < p.split) ? sigmoidf_(v[e]) : tanhf(v[e]);

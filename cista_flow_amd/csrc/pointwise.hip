@@ -503,6 +503,83 @@ hipError_t launch_upflow(const float* coords1, int B, int h8, int w8, int ds, fl
 }
 
 // ---------------------------------------------------------------------------
+// learned convex up-sampling: one wave = one 1/8-res pixel, lane = (i, j) of its 8x8 output patch
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void convex_upsample_kernel(const float* __restrict__ coords1, int coords_is_flow,
+                                                              const float* __restrict__ mask, int mask_ld, int B, int h8,
+                                                              int w8, float* flow_up, float* flow_final, int H, int W,
+                                                              int padH, int padW, int* flag) {
+    const int lane = threadIdx.x & 63;
+    const long N = (long)h8 * w8;
+    const long qid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    bool nz = false;
+    if (qid < (long)B * N) {
+        const int b = (int)(qid / N);
+        const int pix = (int)(qid % N);
+        const int y = pix / w8, x = pix % w8;
+        const float* m = mask + ((long)b * N + pix) * mask_ld + lane;   // channel k*64 + lane
+        float lg[9];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            lg[k] = m[k * 64];
+            mx = fmaxf(mx, lg[k]);
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            lg[k] = expf(lg[k] - mx);
+            den += lg[k];
+        }
+        const float* cx = coords1 + ((long)b * 2 + 0) * N;
+        const float* cy = coords1 + ((long)b * 2 + 1) * N;
+        float ux = 0.f, uy = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+            float fx = 0.f, fy = 0.f;      // F.unfold pads with zeros
+            if (yy >= 0 && yy < h8 && xx >= 0 && xx < w8) {
+                fx = cx[(long)yy * w8 + xx];
+                fy = cy[(long)yy * w8 + xx];
+                if (!coords_is_flow) {
+                    fx -= (float)xx;
+                    fy -= (float)yy;
+                }
+            }
+            const float wgt = lg[k] / den;
+            ux += wgt * (8.f * fx);
+            uy += wgt * (8.f * fy);
+        }
+        const int i = lane >> 3, j = lane & 7;
+        const int oy = 8 * y + i, ox = 8 * x + j;
+        const int Hp = 8 * h8, Wp = 8 * w8;
+        if (flow_up) {
+            flow_up[(((long)b * 2 + 0) * Hp + oy) * Wp + ox] = ux;
+            flow_up[(((long)b * 2 + 1) * Hp + oy) * Wp + ox] = uy;
+        }
+        if (flow_final && oy >= padH && ox >= padW) {
+            flow_final[(((long)b * 2 + 0) * H + (oy - padH)) * W + (ox - padW)] = ux;
+            flow_final[(((long)b * 2 + 1) * H + (oy - padH)) * W + (ox - padW)] = uy;
+            nz = (ux != 0.0f) || (uy != 0.0f);
+        }
+    }
+    if (flag && __any(nz)) {
+        if (lane == 0) *flag = 1;
+    }
+}
+
+hipError_t launch_convex_upsample(const float* coords1, int coords_is_flow, const float* mask, int mask_ld, int B, int h8,
+                                  int w8, float* flow_up, float* flow_final, int H, int W, int padH, int padW, int* flag,
+                                  hipStream_t s) {
+    if (!coords1 || !mask || mask_ld < 576 || B <= 0 || h8 <= 0 || w8 <= 0) return hipErrorInvalidValue;
+    if (flow_final && (H + padH != h8 * 8 || W + padW != w8 * 8)) return hipErrorInvalidValue;
+    const long nq = (long)B * h8 * w8;
+    hipLaunchKernelGGL(convex_upsample_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, coords1, coords_is_flow,
+                       mask, mask_ld, B, h8, w8, flow_up, flow_final, H, W, padH, padW, flag);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // boundary shuffles (recurrent states arrive / leave as whatever the caller holds)
 // ---------------------------------------------------------------------------
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int dst_ld, int B, int C,

@@ -18,6 +18,7 @@ from .. import lib as _lib
 from ..runtime import HipBackend, empty_nhwc, nhwc_state
 from ..utils.flow_utils import FrameWarp
 from ..DCEIFlow.DCEIFlow import DCEIFlow
+from ..ERAFT.eraft import ERAFT
 from .base_layers import *   # noqa: F401,F403  (the reference re-exports the layer library the same way)
 from .base_layers import ConvLayer, ConvLSTC, IstaBlock, RecurrentConvLayer, UpsampleConvLayer
 
@@ -106,39 +107,21 @@ class BaseFlowRec(nn.Module):
         raise NotImplementedError("fix_params is training-only (e2v_model.py:116-133); this build is the inference hot path")
 
 
-class DCEIFlowCistaNet(BaseFlowRec):
-    '''CISTA-Flow: CISTA-LSTC + DCEIFlow  (e2v_model.py:138-196)'''
-
-    def __init__(self, args):
-        super(DCEIFlowCistaNet, self).__init__(args)
-        self.event_flownet = DCEIFlow(num_bins=self.num_bins, args=args)
-        self.flow_iters = 6          # DCEIFlow.forward default iters (DCEIFlow.py:143)
-        self._backend = None
+class _HipFlowRec(BaseFlowRec):
+    """Shared forward of the flow-compensated wrappers: one cf_step call (a5)."""
+    _mode = None
+    flow_iters = 0
 
     def _be(self):
         if self._backend is None:
-            self._backend = HipBackend(self, _lib.CF_MODE_EIFLOW, self.image_dim, num_bins=self.num_bins,
+            self._backend = HipBackend(self, self._mode, self.image_dim, num_bins=self.num_bins,
                                        base_channels=self.cista_net.base_channels, depth=self.cista_net.depth,
                                        iters=self.flow_iters, warp_mode=self.warp_mode)
         return self._backend
 
-    def forward(self, batch_data, states, batch_gt=dict([])):
-        '''batch_data: event_voxel [B,bins,H,W], rec_img0 [B,1,H,W], optional flow_init;
-        states: None | [c, z, (h, cc)]; batch_gt: optional gt_img0 (flow-net image), gt_flow (warp override).
-        Returns (I_rec, batch_flow dict, states).  Like the reference, a non-None `states` list is mutated:
-        states[1] becomes the warped sparse code (e2v_model.py:191).'''
-        if 'event_voxel_bw' in batch_data or 'gt_img1' in batch_gt:
-            raise NotImplementedError("event_voxel_bw / gt_img1 feed the training-only bilateral branch")
-        ev = batch_data['event_voxel']
-        rec0 = batch_data['rec_img0']
-        img_flow = batch_gt['gt_img0'] if 'gt_img0' in batch_gt else rec0
-        flow_init = batch_data.get('flow_init')
-        gt_flow = batch_gt.get('gt_flow')
+    def _step(self, in0, in1, rec0, states, flow_init, gt_flow):
         H, W = self.image_dim
-        B = ev.shape[0]
-        _lib.check_f32_cuda(ev, "event_voxel", (B, self.num_bins, H, W))
-        _lib.check_f32_cuda(rec0, "rec_img0", (B, 1, H, W))
-        _lib.check_f32_cuda(img_flow, "gt_img0", (B, 1, H, W))
+        B = rec0.shape[0]
         fnet = self.event_flownet
         Hp, Wp = fnet.image_padder.padded_size()
         h8, w8 = Hp // 8, Wp // 8
@@ -148,7 +131,7 @@ class DCEIFlowCistaNet(BaseFlowRec):
         if gt_flow is not None:
             _lib.check_f32_cuda(gt_flow, "gt_flow", (B, 2, H, W))
             gt_flow = gt_flow.contiguous()
-        dev = ev.device
+        dev = rec0.device
         cn = self.cista_net
         c_prev, z_prev, h_prev, cc_prev = cn.unpack_states(states, B)
         s2, s1 = cn.state_shapes(B)
@@ -162,7 +145,7 @@ class DCEIFlowCistaNet(BaseFlowRec):
         hh, cc = empty_nhwc(*s1, dev), empty_nhwc(*s1, dev)
         h = self._be().get(B, dev)
         p = _lib.ptr
-        h.check(h.lib.cf_step(h.h, p(ev.contiguous()), p(img_flow.contiguous()), p(rec0.contiguous()), p(flow_init),
+        h.check(h.lib.cf_step(h.h, p(in0.contiguous()), p(in1.contiguous()), p(rec0.contiguous()), p(flow_init),
                               p(gt_flow), p(c_prev), p(z_prev), p(h_prev), p(cc_prev), p(I), p(flow_final), p(flow_low),
                               p(preds), p(z_warp), p(c), p(z), p(hh), p(cc), _lib.current_stream_ptr()), "cf_step")
         if z_warp is not None:
@@ -170,3 +153,54 @@ class DCEIFlowCistaNet(BaseFlowRec):
         batch_flow = dict(flow_preds=[preds[i] for i in range(iters)] if preds is not None else [],
                           flow_init=flow_low, flow_final=flow_final)
         return I, batch_flow, [c, z, (hh, cc)]
+
+
+class DCEIFlowCistaNet(_HipFlowRec):
+    '''CISTA-Flow: CISTA-LSTC + DCEIFlow  (e2v_model.py:138-196)'''
+    _mode = _lib.CF_MODE_EIFLOW
+
+    def __init__(self, args):
+        super(DCEIFlowCistaNet, self).__init__(args)
+        self.event_flownet = DCEIFlow(num_bins=self.num_bins, args=args)
+        self.flow_iters = 6          # DCEIFlow.forward default iters (DCEIFlow.py:143)
+        self._backend = None
+
+    def forward(self, batch_data, states, batch_gt=dict([])):
+        '''batch_data: event_voxel [B,bins,H,W], rec_img0 [B,1,H,W], optional flow_init;
+        states: None | [c, z, (h, cc)]; batch_gt: optional gt_img0 (flow-net image), gt_flow (warp override).
+        Returns (I_rec, batch_flow dict, states).  Like the reference, a non-None `states` list is mutated:
+        states[1] becomes the warped sparse code (e2v_model.py:191).'''
+        if 'event_voxel_bw' in batch_data or 'gt_img1' in batch_gt:
+            raise NotImplementedError("event_voxel_bw / gt_img1 feed the training-only bilateral branch")
+        ev = batch_data['event_voxel']
+        rec0 = batch_data['rec_img0']
+        img_flow = batch_gt['gt_img0'] if 'gt_img0' in batch_gt else rec0
+        H, W = self.image_dim
+        B = ev.shape[0]
+        _lib.check_f32_cuda(ev, "event_voxel", (B, self.num_bins, H, W))
+        _lib.check_f32_cuda(rec0, "rec_img0", (B, 1, H, W))
+        _lib.check_f32_cuda(img_flow, "gt_img0", (B, 1, H, W))
+        return self._step(ev, img_flow, rec0, states, batch_data.get('flow_init'), batch_gt.get('gt_flow'))
+
+
+class ERAFTCistaNet(_HipFlowRec):
+    '''CISTA-Flow: CISTA-LSTC + E-RAFT  (e2v_model.py:200-248)'''
+    _mode = _lib.CF_MODE_ERAFT
+
+    def __init__(self, args):
+        super(ERAFTCistaNet, self).__init__(args)
+        self.event_flownet = ERAFT(args)
+        self.flow_iters = 12         # ERAFT.forward default iters (eraft.py:114)
+        self._backend = None
+
+    def forward(self, batch_data, states, batch_gt=dict([])):
+        '''batch_data: event_voxel_old, event_voxel [B,bins,H,W], rec_img0 [B,1,H,W]; batch_gt: optional gt_flow.'''
+        ev_old = batch_data['event_voxel_old']
+        ev = batch_data['event_voxel']
+        rec0 = batch_data['rec_img0']
+        H, W = self.image_dim
+        B = ev.shape[0]
+        _lib.check_f32_cuda(ev_old, "event_voxel_old", (B, self.num_bins, H, W))
+        _lib.check_f32_cuda(ev, "event_voxel", (B, self.num_bins, H, W))
+        _lib.check_f32_cuda(rec0, "rec_img0", (B, 1, H, W))
+        return self._step(ev_old, ev, rec0, states, None, batch_gt.get('gt_flow'))

@@ -371,3 +371,92 @@ def eiflow_step(sd, batch_data, states, warp_mode="forward", depth=5, iters=6, g
             states[1] = warp(states[1], dflow, warp_mode)
     I_rec, new_states = cista_forward(sd, batch_data["event_voxel"], warped_I, states, depth=depth)
     return I_rec, bf, new_states
+
+
+# ----------------------------------------------------------------------------------------------
+# E-RAFT  (a12, a14)   /root/reference/ERAFT/eraft.py:77-88,114-178 ; ERAFT/update.py:63-106 ;
+#                      ERAFT/extractor.py:119-189 ; ERAFT/corr.py:12-60 ; e2v/e2v_model.py:206-248
+# ----------------------------------------------------------------------------------------------
+
+
+def convex_upsample(flow, mask):
+    """ERAFT.upsample_flow: softmax over the 9 neighbours of mask [B,576,h,w] (channel k*64+i*8+j) applied to
+    unfold(8*flow, 3x3, padding=1); output [B,2,8h,8w]."""
+    B, _, h, w = flow.shape
+    m = torch.softmax(mask.reshape(B, 1, 9, 8, 8, h, w), dim=2)
+    fp = F.pad(8 * flow, (1, 1, 1, 1))
+    nb = torch.stack([fp[:, :, dy:dy + h, dx:dx + w] for dy in range(3) for dx in range(3)], dim=2)   # [B,2,9,h,w]
+    up = (m * nb.reshape(B, 2, 9, 1, 1, h, w)).sum(dim=2)            # [B,2,8,8,h,w]
+    return up.permute(0, 1, 4, 2, 5, 3).reshape(B, 2, 8 * h, 8 * w)
+
+
+def eraft_update_block(sd, pre, net, inp, corr, flow):
+    """ERAFT BasicUpdateBlock: motion encoder (no emap branch) + SepConvGRU + FlowHead + mask head."""
+    e = pre + ".encoder."
+
+    def c(name, x, pad):
+        return conv2d(x, sd[name + ".weight"], sd[name + ".bias"], 1, pad)
+
+    cor = torch.relu(c(e + "convc1", corr, (0, 0)))
+    cor = torch.relu(c(e + "convc2", cor, (1, 1)))
+    flo = torch.relu(c(e + "convf1", flow, (3, 3)))
+    flo = torch.relu(c(e + "convf2", flo, (1, 1)))
+    out = torch.relu(c(e + "conv", torch.cat([cor, flo], 1), (1, 1)))
+    x = torch.cat([inp, out, flow], 1)
+    g = pre + ".gru."
+    h = net
+    for sfx, pad in (("1", (0, 2)), ("2", (2, 0))):
+        hx = torch.cat([h, x], 1)
+        z = torch.sigmoid(c(g + "convz" + sfx, hx, pad))
+        r = torch.sigmoid(c(g + "convr" + sfx, hx, pad))
+        q = torch.tanh(c(g + "convq" + sfx, torch.cat([r * h, x], 1), pad))
+        h = (1 - z) * h + z * q
+    fh = pre + ".flow_head."
+    delta = c(fh + "conv2", torch.relu(c(fh + "conv1", h, (1, 1))), (1, 1))
+    mask = 0.25 * c(pre + ".mask.2", torch.relu(c(pre + ".mask.0", h, (1, 1))), (0, 0))
+    return h, mask, delta
+
+
+def eraft_forward(sd, image1, image2, iters=12, flow_init=None, prefix="event_flownet."):
+    """ERAFT.forward: image1 / image2 are the old / new event voxel grids."""
+    p = prefix
+    B, _, H, W = image1.shape
+    image1, ph, pw = image_pad(image1, H, W)
+    image2, _, _ = image_pad(image2, H, W)
+    fmap1 = encoder(sd, p + "fnet", image1, "instance")
+    fmap2 = encoder(sd, p + "fnet", image2, "instance")
+    pyr = corr_pyramid(fmap1, fmap2)
+    cnet = encoder(sd, p + "cnet", image2, "batch")
+    net, inp = torch.tanh(cnet[:, :128]), torch.relu(cnet[:, 128:])
+    h8, w8 = image1.shape[2] // 8, image1.shape[3] // 8
+    coords0 = coords_grid(B, h8, w8)
+    coords1 = coords_grid(B, h8, w8)
+    if flow_init is not None:
+        coords1 = coords1 + flow_init
+    preds = []
+    flow_up = None
+    for _ in range(iters):
+        corr = corr_lookup(pyr, coords1)
+        flow = coords1 - coords0
+        net, mask, delta = eraft_update_block(sd, p + "update_block", net, inp, corr, flow)
+        coords1 = coords1 + delta
+        up = convex_upsample(coords1 - coords0, mask)
+        preds.append(up)
+        flow_up = up[..., ph:, pw:]
+    return dict(flow_preds=preds, flow_init=coords1 - coords0, flow_final=flow_up)
+
+
+def eraft_step(sd, batch_data, states, warp_mode="forward", depth=5, iters=12, gt_flow=None):
+    """ERAFTCistaNet.forward: flow from (event_voxel_old, event_voxel), then the shared warp + CISTA tail."""
+    bf = eraft_forward(sd, batch_data["event_voxel_old"], batch_data["event_voxel"], iters=iters)
+    flow_final = bf["flow_final"] if gt_flow is None else gt_flow
+    if not flow_final.any():
+        warped_I = batch_data["rec_img0"]
+    else:
+        warped_I = warp(batch_data["rec_img0"], flow_final, warp_mode)
+        if states is not None:
+            H, W = flow_final.shape[-2:]
+            dflow = interp_bilinear(flow_final, H // 2, W // 2, align_corners=True)
+            states[1] = warp(states[1], dflow, warp_mode)
+    I_rec, new_states = cista_forward(sd, batch_data["event_voxel"], warped_I, states, depth=depth)
+    return I_rec, bf, new_states

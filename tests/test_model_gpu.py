@@ -94,6 +94,52 @@ def test_eiflow_golden_sequence(gpu, name, mode):
             prev = I.clone()
 
 
+def test_eraft_golden_sequence(gpu):
+    """cista-eraft (BASELINE configs[2]) with the driver's evs_old carry (test_with_flow.py:144-149)."""
+    from cista_flow_amd.e2v.e2v_model import ERAFTCistaNet
+    g = gu.load("eraft_100x124.npz")
+    H, W, B, frames, seed = [int(v) for v in g["meta"]]
+    m = ERAFTCistaNet(args_for(H, W)).eval()
+    wu.fill_module(m, seed)
+    m = m.to(gpu)
+    states, prev, ev_old = None, torch.zeros(B, 1, H, W, device=gpu), None
+    with torch.no_grad():
+        for t in range(frames):
+            ev = torch.from_numpy(g["ev_%d" % t]).to(gpu)
+            if ev_old is None:
+                ev_old = wu.synth_events(B, 5, H, W, seed * 1000 + 999).to(gpu)   # see tools/gen_golden.py::run_eraft
+            I, bf, states = m({"event_voxel": ev, "event_voxel_old": ev_old, "rec_img0": prev}, states, {})
+            ev_old = ev.clone()
+            assert gu.rel_err(bf["flow_final"].cpu(), g["flow_%d" % t]) < TOL, t
+            assert gu.rel_err(bf["flow_init"].cpu(), g["flowlow_%d" % t]) < TOL, t
+            assert gu.rel_err(I.cpu(), g["I_%d" % t]) < TOL, t
+            assert gu.rel_err(gu.sub(states[0].cpu()), g["c_%d" % t]) < TOL, t
+            assert gu.rel_err(gu.sub(states[1].cpu()), g["z_%d" % t]) < TOL, t
+            assert gu.rel_err(gu.sub(states[2][0].cpu()), g["h_%d" % t]) < TOL, t
+            if t == 1:
+                assert len(bf["flow_preds"]) == 12
+                assert gu.rel_err(bf["flow_preds"][0].cpu(), g["preds0_1"]) < TOL
+                assert gu.rel_err(bf["flow_preds"][6].cpu(), g["preds6_1"]) < TOL
+            prev = I.clone()
+
+
+def test_eraft_last_only_matches_full(gpu):
+    """return_flow_preds=False skips the 11 dead mask-head / up-sampling evaluations; flow_final is unchanged."""
+    from cista_flow_amd.ERAFT.eraft import ERAFT
+    H, W, B = 128, 160, 2
+    net = ERAFT(args_for(H, W)).eval()
+    wu.fill_module(net, 9)
+    net = net.to(gpu)
+    a, b = wu.synth_events(B, 5, H, W, 1).to(gpu), wu.synth_events(B, 5, H, W, 2).to(gpu)
+    with torch.no_grad():
+        full = net(a, b)
+        net.return_flow_preds = False
+        last = net(a, b)
+    assert last["flow_preds"] == []
+    assert torch.equal(full["flow_final"], last["flow_final"])
+    assert torch.equal(full["flow_preds"][-1][..., net.image_padder.pad_height:, net.image_padder.pad_width:], full["flow_final"])
+
+
 def test_eiflow_vs_oracle_fresh_inputs(gpu):
     """B=3, 132x164 (pads to 160x192), 3 frames, seeds not used by any fixture; every output and full states."""
     from oracle import cista_oracle as orc

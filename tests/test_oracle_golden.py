@@ -71,15 +71,40 @@ def test_eiflow_golden(name, mode):
         prev = I.clone()
 
 
+def test_eraft_golden():
+    g = gu.load("eraft_100x124.npz")
+    H, W, B, frames, seed = [int(v) for v in g["meta"]]
+    sd = wu.make_state_dict(gu.layout("eraft_state_dict_layout.json"), seed)
+    states, prev, ev_old = None, torch.zeros(B, 1, H, W), None
+    for t in range(frames):
+        ev = torch.from_numpy(g["ev_%d" % t])
+        if ev_old is None:
+            ev_old = wu.synth_events(B, 5, H, W, seed * 1000 + 999)   # see tools/gen_golden.py::run_eraft
+        I, bf, states = orc.eraft_step(sd, {"event_voxel": ev, "event_voxel_old": ev_old, "rec_img0": prev}, states)
+        ev_old = ev.clone()
+        assert gu.rel_err(bf["flow_final"], g["flow_%d" % t]) < 5e-5, t
+        assert gu.rel_err(bf["flow_init"], g["flowlow_%d" % t]) < 5e-5, t
+        assert gu.rel_err(I, g["I_%d" % t]) < 5e-5, t
+        assert gu.rel_err(gu.sub(states[1]), g["z_%d" % t]) < 5e-5, t
+        assert gu.rel_err(gu.sub(states[0]), g["c_%d" % t]) < 5e-5, t
+        if t == 1:
+            assert len(bf["flow_preds"]) == 12
+            assert gu.rel_err(bf["flow_preds"][0], g["preds0_1"]) < 5e-5
+            assert gu.rel_err(bf["flow_preds"][6], g["preds6_1"]) < 5e-5
+        prev = I.clone()
+
+
 def test_state_dict_layout_matches_reference():
     """The shell modules must expose the reference's state_dict keys, shapes and order (262 entries)."""
     import argparse
-    from cista_flow_amd.e2v.e2v_model import CistaLSTCNet, DCEIFlowCistaNet
+    from cista_flow_amd.e2v.e2v_model import CistaLSTCNet, DCEIFlowCistaNet, ERAFTCistaNet
     a = argparse.Namespace(image_dim=[180, 240], num_bins=5, warp_mode='forward', base_channels=64, depth=5, ds=8, is_bi=False)
     m = DCEIFlowCistaNet(a)
     assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == gu.layout("eiflow_state_dict_layout.json")
     c = CistaLSTCNet([180, 240])
     assert [(k, tuple(v.shape)) for k, v in c.state_dict().items()] == gu.layout("cista_state_dict_layout.json")
+    e = ERAFTCistaNet(a)
+    assert [(k, tuple(v.shape)) for k, v in e.state_dict().items()] == gu.layout("eraft_state_dict_layout.json")
     # the five lista blocks alias one storage and survive a strict load
     sd = wu.make_state_dict(gu.layout("eiflow_state_dict_layout.json"), 5)
     m.load_state_dict(sd, strict=True)

@@ -43,6 +43,8 @@ def make_tensor(key, shape, seed):
             gain = 6.0
         elif "flow_head.conv2" in ck:
             gain = 0.08
+        elif "update_block.mask.2" in ck:
+            gain = 3.0       # spread the convex-upsampling logits so the softmax is not uniform
         elif ck.startswith("cista_net") or not ("fnet" in ck or "cnet" in ck or "enet" in ck or "update_block" in ck or "fusion" in ck):
             gain = 1.5
         else:

@@ -78,6 +78,43 @@ def run_eiflow(ref_model, H, W, B, frames, seed, warp_mode, name, keep_inter=Fal
     return model
 
 
+def run_eraft(ref_model, H, W, B, frames, seed, name):
+    """driver loop of test_with_flow.py:144-149 (evs_old = previous voxel grid).  The driver starts with
+    evs_old = zeros; that input is numerically degenerate in the reference itself -- conv1(0) is a constant
+    field, InstanceNorm2d divides its rounding noise by sqrt(eps) and the next InstanceNorm2d rescales that noise
+    to unit variance, so frame-0 features are implementation-defined noise -- hence the fixture starts from a
+    random previous grid instead."""
+    from weights_util import fill_module, synth_events
+    torch.manual_seed(0)
+    model = ref_model.ERAFTCistaNet(ns(H, W)).eval()
+    fill_module(model, seed)
+    out = {"meta": np.array([H, W, B, frames, seed], dtype=np.int64)}
+    states = None
+    prev = torch.zeros(B, 1, H, W)
+    evs_old = None
+    with torch.no_grad():
+        for t in range(frames):
+            ev = synth_events(B, 5, H, W, seed * 1000 + t)
+            if evs_old is None:
+                evs_old = synth_events(B, 5, H, W, seed * 1000 + 999)
+            I, bf, states = model({"event_voxel": ev, "event_voxel_old": evs_old, "rec_img0": prev}, states, {})
+            evs_old = ev.clone()
+            out["ev_%d" % t] = ev.numpy()
+            out["I_%d" % t] = I.numpy()
+            out["flow_%d" % t] = bf["flow_final"].numpy()
+            out["flowlow_%d" % t] = bf["flow_init"].numpy()
+            out["c_%d" % t] = sub(states[0])
+            out["z_%d" % t] = sub(states[1])
+            out["h_%d" % t] = sub(states[2][0])
+            out["cc_%d" % t] = sub(states[2][1])
+            if t == 1:
+                out["preds0_1"] = bf["flow_preds"][0].numpy()
+                out["preds6_1"] = bf["flow_preds"][6].numpy()
+            prev = I.clone()
+    np.savez_compressed(os.path.join(GOLD, name), **out)
+    print(name)
+
+
 def run_cista(ref_model, H, W, B, frames, seed, name):
     from weights_util import fill_module, synth_events
     torch.manual_seed(0)
@@ -128,6 +165,13 @@ def main():
     c = ref_model.CistaLSTCNet([180, 240])
     with open(os.path.join(GOLD, "cista_state_dict_layout.json"), "w") as f:
         json.dump([[k, list(v.shape)] for k, v in c.state_dict().items()], f)
+    e = ref_model.ERAFTCistaNet(ns(180, 240))
+    with open(os.path.join(GOLD, "eraft_state_dict_layout.json"), "w") as f:
+        json.dump([[k, list(v.shape)] for k, v in e.state_dict().items()], f)
+    if "--only-new" in sys.argv:
+        run_eraft(ref_model, 100, 124, 2, 3, 31, "eraft_100x124.npz")
+        return
+    run_eraft(ref_model, 100, 124, 2, 3, 31, "eraft_100x124.npz")
     run_warp(ref_flow, "warp.npz")
     run_cista(ref_model, 36, 52, 2, 3, 11, "cista_36x52.npz")
     # 100x124 pads (top 28 / left 4) to 128x128: the smallest padded size whose 4th pyramid level is still
