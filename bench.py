@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=3)
+    ap.add_argument("--model", default="eiflow", choices=["eiflow", "eraft", "idnet"],
+                    help="flow network (the BASELINE metric is eiflow; the others are extra workloads)")
     return ap.parse_args()
 
 
@@ -95,22 +97,31 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     import weights_util as wu
-    from cista_flow_amd.e2v.e2v_model import DCEIFlowCistaNet
+    from cista_flow_amd.e2v.e2v_model import DCEIFlowCistaNet, ERAFTCistaNet, IDCistaNet
     from cista_flow_amd.parallel import collate_frames
     B, H, W = a.batch, a.height, a.width
-    model = DCEIFlowCistaNet(model_args(H, W)).eval()
+    cls = {"eiflow": DCEIFlowCistaNet, "eraft": ERAFTCistaNet, "idnet": IDCistaNet}[a.model]
+    model = cls(model_args(H, W)).eval()
     wu.fill_module(model, 1234)
     model = model.to(dev)
-    model.event_flownet.return_flow_preds = True      # like the reference: every iteration's up-flow is produced
+    if a.model != "idnet":
+        model.event_flownet.return_flow_preds = True  # like the reference: every iteration's up-flow is produced
     R = 8
     evs = [wu.synth_events(B, 5, H, W, 1234 + 100 * rank + i).to(dev) for i in range(R)]
     side = torch.cuda.Stream(device=dev) if world > 1 else None
 
-    state = {"prev": torch.zeros(B, 1, H, W, device=dev), "states": None, "i": 0}
+    state = {"prev": torch.zeros(B, 1, H, W, device=dev), "states": None, "i": 0, "flow_init": None}
 
     def step():
         ev = evs[state["i"] % R]
-        I, bf, st = model({"event_voxel": ev, "rec_img0": state["prev"]}, state["states"], {})
+        if a.model == "eiflow":
+            I, bf, st = model({"event_voxel": ev, "rec_img0": state["prev"]}, state["states"], {})
+        elif a.model == "eraft":     # test_with_flow.py:144-149 (the previous voxel grid; a non-degenerate one on frame 0)
+            I, bf, st = model({"event_voxel": ev, "event_voxel_old": evs[(state["i"] - 1) % R], "rec_img0": state["prev"]},
+                              state["states"], {})
+        else:                        # test_with_flow.py:150-154
+            I, bf, st = model({"event_voxel": ev, "rec_img0": state["prev"]}, state["states"], state["flow_init"], {})
+            state["flow_init"] = bf["next_flow"]
         state["prev"], state["states"] = I, st
         state["i"] += 1
         if world > 1:
@@ -185,17 +196,18 @@ def main():
         }
 
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.model == "eiflow":
         cpu = cpu_baseline(B, H, W, a.cpu_frames)
 
     if rank == 0:
         value = world * B * a.steps / el
         out = {
-            "metric": "reconstructed frames/sec at 180x240, cista-eiflow", "value": round(value, 2), "unit": "frames/s",
+            "metric": "reconstructed frames/sec at %dx%d, cista-%s" % (H, W, a.model), "value": round(value, 2), "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "cista-eiflow %dx%d batch=%d sequences per GPU (BASELINE configs[1]), DCEIFlow 6 iters, "
-                                   "CISTA depth 5, seeded random weights" % (H, W, B),
+            "config": {"workload": "cista-%s %dx%d batch=%d sequences per GPU (BASELINE configs[%d]), flow iters %d, "
+                                   "CISTA depth 5, seeded random weights" % (a.model, H, W, B, {"eiflow": 1, "eraft": 2, "idnet": 4}[a.model],
+                                                                            model.flow_iters),
                        "sequences_per_gpu": B, "height": H, "width": W, "parallelism": "dp%d (independent sequences)" % world},
             "roofline": roofline, "cpu_baseline": cpu,
         }

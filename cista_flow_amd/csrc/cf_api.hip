@@ -100,7 +100,10 @@ struct cf_handle {
     float *coords1 = nullptr, *corrfeat = nullptr, *c1buf = nullptr, *mcat = nullptr, *e1buf = nullptr, *f1buf = nullptr,
           *motion = nullptr, *zbuf = nullptr, *rh = nullptr, *fh = nullptr;
     float* gpre[2] = {nullptr, nullptr};
-    float *mask1 = nullptr, *maskbuf = nullptr;   // ERAFT mask head
+    float *mask1 = nullptr, *maskbuf = nullptr;   // ERAFT / IDNet mask head
+    // IDNet
+    float *idDeblur = nullptr, *idA = nullptr, *idB = nullptr, *idC = nullptr, *idD = nullptr, *idF = nullptr,
+          *idNet = nullptr, *idZ = nullptr, *idRH = nullptr, *idFH = nullptr, *idDflow = nullptr, *idDelta = nullptr;
     static constexpr int CORR_LD = 336;   // 4*81 = 324 correlation channels padded to a multiple of 16
 
     // per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
@@ -210,6 +213,23 @@ static void setup_buffers(cf_handle* H_) {
             s.maskbuf = a.f(B * N * 576);
         }
     }
+    if (s.cfg.mode == CF_MODE_IDNET) {
+        const size_t P1 = (size_t)s.H1 * s.W1, N = s.N, T = s.cfg.num_bins;
+        s.idDeblur = a.f(B * T * (size_t)s.Hp * s.Wp);
+        s.idA = a.f(B * T * P1 * 32);
+        s.idB = a.f(B * T * P1 * 32);
+        s.idC = a.f(B * T * P1 * 32);
+        s.idD = a.f(B * T * P1 * 32);
+        s.idF = a.f(B * T * N * 64);
+        s.idNet = a.f(B * N * 96);
+        s.idZ = a.f(B * N * 96);
+        s.idRH = a.f(B * N * 96);
+        s.idFH = a.f(B * N * 96);
+        s.idDflow = a.f(B * 2 * N);
+        s.idDelta = a.f(B * 2 * (size_t)s.Hp * s.Wp);
+        s.mask1 = a.f(B * N * 256);
+        s.maskbuf = a.f(B * N * 576);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -288,7 +308,7 @@ static const RawWeight* find_raw(cf_handle* h, const std::string& name) {
     return it == h->raw.end() ? nullptr : &it->second;
 }
 
-struct CinSlice { int begin, count, dst; };
+struct CinSlice { int begin, count, dst; int accum = 0; };
 
 // Packs `prefix`.weight/.bias (OIHW) as rows [row0, row0+Cout) of the conv registered under `key`.
 // total_rows > 0 on the first call allocates the packed matrix; bn_prefix folds an eval BatchNorm.
@@ -303,13 +323,13 @@ static int pack_conv(cf_handle* h, const std::string& key, const std::string& pr
     const int Cout = (int)wt->shape[0], Cin = (int)wt->shape[1], KH = (int)wt->shape[2], KW = (int)wt->shape[3];
     if (bs && (bs->shape.size() != 1 || bs->shape[0] != Cout)) return h->fail(CF_ERR_WEIGHT, "bad bias shape: " + prefix);
     const int cin_eff = slices.empty() ? Cin : packed_cin;
-    if (!slices.empty() && (gather || packed_cin <= 0)) return h->fail(CF_ERR_WEIGHT, "bad slice spec: " + prefix);
+    if (!slices.empty() && packed_cin <= 0) return h->fail(CF_ERR_WEIGHT, "bad slice spec: " + prefix);
     PackedConv& pc = h->conv[key];
     pc.name = key;
     if (!pc.w) {
         pc.cin = cin_eff; pc.KH = KH; pc.KW = KW; pc.gather = gather;
         pc.cin_pad = gather ? 0 : round_up(cin_eff, 16);
-        pc.Ktot = gather ? round_up(KH * KW * Cin, 16) : KH * KW * pc.cin_pad;
+        pc.Ktot = gather ? round_up(KH * KW * cin_eff, 16) : KH * KW * pc.cin_pad;
         pc.cout = total_rows > 0 ? total_rows : Cout;
         pc.rows = round_up(pc.cout, 128);
         const size_t wbytes = (size_t)pc.rows * pc.Ktot * sizeof(float);
@@ -336,12 +356,12 @@ static int pack_conv(cf_handle* h, const std::string& key, const std::string& pr
     }
     const float* bsrc = (bs && with_bias) ? bs->ptr : nullptr;
     if (slices.empty()) {
-        CF_HIP(h, launch_pack_weight(wt->ptr, pc.w, Cout, Cin, KH, KW, pc.cin_pad, pc.Ktot, row0, gather ? 1 : 0, 0, 0, 0, bw,
+        CF_HIP(h, launch_pack_weight(wt->ptr, pc.w, Cout, Cin, KH, KW, pc.cin_pad, pc.Ktot, row0, gather ? 1 : 0, 0, 0, 0, 0, bw,
                                      bb, bm, bv, 1e-5f, bsrc, pc.bias, st));
     } else {
         for (const CinSlice& sl : slices)
-            CF_HIP(h, launch_pack_weight(wt->ptr, pc.w, Cout, Cin, KH, KW, pc.cin_pad, pc.Ktot, row0, 0, sl.begin, sl.count,
-                                         sl.dst, bw, bb, bm, bv, 1e-5f, bsrc, pc.bias, st));
+            CF_HIP(h, launch_pack_weight(wt->ptr, pc.w, Cout, Cin, KH, KW, pc.cin_pad, pc.Ktot, row0, gather ? 1 : 0, sl.begin,
+                                         sl.count, sl.dst, sl.accum, bw, bb, bm, bv, 1e-5f, bsrc, pc.bias, st));
     }
     return CF_OK;
 }
@@ -394,6 +414,7 @@ extern "C" int cf_finalize_weights(cf_handle* h, void* stream) {
     if (find_raw(h, "event_flownet.fnet.conv1.weight")) { fn = "event_flownet."; got_flow = true; }
     else if (find_raw(h, "fnet.conv1.weight")) { fn = ""; got_flow = true; }
     if (!got_cista && !got_flow) return h->fail(CF_ERR_WEIGHT, "cf_finalize_weights: no known weights were announced");
+    if (h->cfg.mode == CF_MODE_IDNET) got_flow = false;   // IDNet's fnet is packed by its own block below
     if (got_cista) {
         auto C = [&](const std::string& key, const std::string& name, bool gather) -> int {
             return pack_conv(h, "cista." + key, cn + name, gather, 0, 0, "", st);
@@ -472,6 +493,41 @@ extern "C" int cf_finalize_weights(cf_handle* h, void* stream) {
             return h->fail(CF_ERR_WEIGHT, "ERAFT weights do not match the handle");
         h->has_flow = true;
     }
+    if (h->cfg.mode == CF_MODE_IDNET) {
+        std::string f;
+        if (find_raw(h, "event_flownet.fnet.conv1.weight")) f = "event_flownet.";
+        else if (find_raw(h, "fnet.conv1.weight")) f = "";
+        else f = "?";
+        if (f != "?") {
+            // LiteEncoder (idn/extractor.py:63-125).  The reference feeds it [bin, bin] (idedeq.py:165): the two
+            // input channels always carry identical data, so conv1's two input-channel slices are summed at
+            // pack time and the encoder reads the bin once.
+            const std::vector<CinSlice> sum2 = {{0, 1, 0, 0}, {1, 1, 0, 1}};
+            if ((rc = pack_conv(h, "idn.fnet.conv1", f + "fnet.conv1", true, 0, 0, "", st, sum2, 1, true))) return rc;
+            for (int L = 1; L <= 2; ++L)
+                for (int blk = 0; blk < 2; ++blk) {
+                    const std::string b = "fnet.layer" + std::to_string(L) + "." + std::to_string(blk);
+                    if ((rc = pack_conv(h, "idn." + b + ".conv1", f + b + ".conv1", false, 0, 0, "", st))) return rc;
+                    if ((rc = pack_conv(h, "idn." + b + ".conv2", f + b + ".conv2", false, 0, 0, "", st))) return rc;
+                    if (blk == 0 && (rc = pack_conv(h, "idn." + b + ".downsample.0", f + b + ".downsample.0", false, 0, 0, "", st))) return rc;
+                }
+            const std::string u = f + "update_net.";
+            // ConvGRU (idn/update.py:29-44): z | r stacked
+            if ((rc = pack_conv(h, "idn.gru.zr", u + "gru.convz", false, 0, 192, "", st))) return rc;
+            if ((rc = pack_conv(h, "idn.gru.zr", u + "gru.convr", false, 96, 192, "", st))) return rc;
+            if ((rc = pack_conv(h, "idn.gru.q", u + "gru.convq", false, 0, 0, "", st))) return rc;
+            for (const char* hd : {"", "2"}) {
+                const std::string k = hd;
+                if ((rc = pack_conv(h, "idn.fh" + k + ".conv1", u + "flow_head" + k + ".conv1", false, 0, 0, "", st))) return rc;
+                if ((rc = pack_conv(h, "idn.fh" + k + ".conv2", u + "flow_head" + k + ".conv2", false, 0, 0, "", st))) return rc;
+                if ((rc = pack_conv(h, "idn.mask" + k + ".0", u + "mask" + k + ".0", false, 0, 0, "", st))) return rc;
+                if ((rc = pack_conv(h, "idn.mask" + k + ".2", u + "mask" + k + ".2", false, 0, 0, "", st))) return rc;
+            }
+            if (h->conv["idn.gru.q"].cin != 160 || h->conv["idn.mask.2"].cout != 576)
+                return h->fail(CF_ERR_WEIGHT, "IDNet weights do not match hidden_dim=96 / downsample=8");
+            h->has_flow = true;
+        }
+    }
     // the announced pointers may die after this call: drain the packing kernels
     CF_HIP(h, hipStreamSynchronize(st));
     h->raw.clear();
@@ -497,10 +553,7 @@ extern "C" int cf_create(cf_handle** out, const cf_config* cfg) {
     if (cfg->num_bins != 5 && cfg->num_bins < 1) return bad("cf_create: bad num_bins");
     if (cfg->base_channels < 32 || (cfg->base_channels % 32) != 0) return bad("cf_create: base_channels must be a multiple of 32");
     if (cfg->depth < 1) return bad("cf_create: bad depth");
-    if (cfg->mode != CF_MODE_CISTA && cfg->mode != CF_MODE_EIFLOW && cfg->mode != CF_MODE_ERAFT) {
-        g_create_error = "cf_create: mode not built yet (idnet)";
-        return CF_ERR_UNSUPPORTED;
-    }
+    if (cfg->mode < CF_MODE_CISTA || cfg->mode > CF_MODE_IDNET) return bad("cf_create: unknown mode");
     if ((cfg->mode == CF_MODE_EIFLOW || cfg->mode == CF_MODE_ERAFT) && cfg->iters < 1) return bad("cf_create: bad iters");
     cf_handle* h = new cf_handle();
     h->cfg = *cfg;
@@ -958,7 +1011,7 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
             m2.scale = 0.25f;
             CF_HIP(h, run_conv(h, m2, B, st));
             CF_HIP(h, launch_convex_upsample(h->coords1, 0, h->maskbuf, 576, B, h8, w8, up, last ? flow_final : nullptr, h->H,
-                                             h->W, h->padH, h->padW, last ? flag : nullptr, st));
+                                             h->W, h->padH, h->padW, last ? flag : nullptr, nullptr, nullptr, st));
         }
     }
     if (flow_low) {
@@ -968,13 +1021,105 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
     return CF_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// IDEDEQIDO.forward  idn/idedeq.py:124-227 (update_iters = 1, pred_next_flow = True as e2v_model.py:256-262 builds it)
+//   flow_init: padded [B][2][Hp][Wp] or NULL; flow_final: [B][2][H][W]; next_flow: padded (nullable);
+//   hist (nullable): [2][B][2][Hp][Wp] = {flow_total ("flow_preds"[0]), delta_flow}
+// ---------------------------------------------------------------------------------------------
+static int idnet_forward(cf_handle* h, const float* ev, const float* flow_init, float* flow_final, float* next_flow,
+                         float* hist, int* flag, hipStream_t st) {
+    const int B = h->B, T = h->cfg.num_bins, h8 = h->h8, w8 = h->w8, Hp = h->Hp, Wp = h->Wp;
+    const long N = h->N;
+    const int BT = B * T;
+    // deblur every bin along the initial flow (zero flow is not an identity: align_corners quirk)
+    CF_HIP(h, launch_idn_deblur(ev, flow_init, h->idDeblur, B, T, h->H, h->W, h->padH, h->padW, st));
+    // LiteEncoder on all B*T bins at once (they are independent of the GRU state)
+    auto K = [&](const std::string& k) -> const PackedConv& { return h->conv["idn." + k]; };
+    int Hc = h->H1, Wc = h->W1;
+    float *A = h->idA, *Bf = h->idB, *Cf = h->idC, *Df = h->idD;
+    {
+        ConvParams p = gather_conv(K("fnet.conv1"), h->idDeblur, 1, Hp, Wp, 0, 0, 1.f, 0.f, 0, Hc, Wc, 2, 3, 3, 0, A, 32,
+                                   (long)Hc * Wc * 32, EPI_RELU);
+        CF_HIP(h, run_conv(h, p, BT, st));
+    }
+    int Cx = 32;
+    const int dims[2] = {32, 64};
+    for (int L = 1; L <= 2; ++L) {
+        const int Cd = dims[L - 1];
+        for (int blk = 0; blk < 2; ++blk) {
+            const std::string b = "fnet.layer" + std::to_string(L) + "." + std::to_string(blk);
+            const int stride = blk == 0 ? 2 : 1;
+            const int Ho = Hc / stride, Wo = Wc / stride;
+            const long ibs = (long)Hc * Wc * Cx, obs = (long)Ho * Wo * Cd;
+            float* out = (L == 2 && blk == 1) ? h->idF : Df;
+            ConvParams c1 = nhwc_conv(K(b + ".conv1"), {{A, Cx, Cx, ibs}}, Hc, Wc, Ho, Wo, stride, 1, 1, 0, Bf, Cd, obs, EPI_RELU);
+            CF_HIP(h, run_conv(h, c1, BT, st));
+            const float* res = A;
+            int res_ld = Cx;
+            long res_bs = ibs;
+            if (stride != 1) {
+                ConvParams ds = nhwc_conv(K(b + ".downsample.0"), {{A, Cx, Cx, ibs}}, Hc, Wc, Ho, Wo, stride, 0, 0, 0, Cf, Cd, obs, EPI_NONE);
+                CF_HIP(h, run_conv(h, ds, BT, st));
+                res = Cf; res_ld = Cd; res_bs = obs;
+            }
+            ConvParams c2 = nhwc_conv(K(b + ".conv2"), {{Bf, Cd, Cd, obs}}, Ho, Wo, Ho, Wo, 1, 1, 1, 0, out, Cd, obs, EPI_RELU_ADD_AUX_RELU);
+            set_aux0(c2, res, res_ld, res_bs);
+            CF_HIP(h, run_conv(h, c2, BT, st));
+            if (out == Df) std::swap(A, Df);
+            Hc = Ho; Wc = Wo; Cx = Cd;
+        }
+    }
+    // ConvGRU over the T bins, h0 = 0 (idedeq.py:181-192)
+    CF_HIP(h, hipMemsetAsync(h->idNet, 0, sizeof(float) * (size_t)B * N * 96, st));
+    for (int t = 0; t < T; ++t) {
+        const float* ft = h->idF + (long)t * N * 64;      // bin t of sequence b sits at batch index b*T + t
+        const long fbs = (long)T * N * 64;
+        ConvParams a = nhwc_conv(K("gru.zr"), {{h->idNet, 96, 96, N * 96}, {ft, 64, 64, fbs}}, h8, w8, h8, w8, 1, 1, 1, 0, h->idZ, 96, N * 96, EPI_GRU_ZR);
+        a.split = 96;
+        set_aux0(a, h->idNet, 96, N * 96);
+        set_out2(a, h->idRH, 96, N * 96);
+        CF_HIP(h, run_conv(h, a, B, st));
+        ConvParams q = nhwc_conv(K("gru.q"), {{h->idRH, 96, 96, N * 96}, {ft, 64, 64, fbs}}, h8, w8, h8, w8, 1, 1, 1, 0, h->idNet, 96, N * 96, EPI_GRU_Q);
+        set_aux0(q, h->idZ, 96, N * 96);
+        set_aux1(q, h->idNet, 96, N * 96);
+        CF_HIP(h, run_conv(h, q, B, st));
+    }
+    if (flag) CF_HIP(h, hipMemsetAsync(flag, 0, sizeof(int), st));
+    // two heads: delta_flow (flow_head / mask) and next_flow (flow_head2 / mask2), each convex-upsampled x8
+    for (int hd = 0; hd < 2; ++hd) {
+        if (hd == 1 && !next_flow) break;
+        const std::string k = hd == 0 ? "" : "2";
+        ConvParams f1 = nhwc_conv(K("fh" + k + ".conv1"), {{h->idNet, 96, 96, N * 96}}, h8, w8, h8, w8, 1, 1, 1, 0, h->idFH, 96, N * 96, EPI_RELU);
+        CF_HIP(h, run_conv(h, f1, B, st));
+        ConvParams f2 = nhwc_conv(K("fh" + k + ".conv2"), {{h->idFH, 96, 96, N * 96}}, h8, w8, h8, w8, 1, 1, 1, 0, h->idDflow, 1, 2 * N, EPI_NONE);
+        f2.out_cs = (int)N;
+        CF_HIP(h, run_conv(h, f2, B, st));
+        ConvParams m0 = nhwc_conv(K("mask" + k + ".0"), {{h->idNet, 96, 96, N * 96}}, h8, w8, h8, w8, 1, 1, 1, 0, h->mask1, 256, N * 256, EPI_RELU);
+        CF_HIP(h, run_conv(h, m0, B, st));
+        ConvParams m2 = nhwc_conv(K("mask" + k + ".2"), {{h->mask1, 256, 256, N * 256}}, h8, w8, h8, w8, 1, 0, 0, 0, h->maskbuf, 576, N * 576, EPI_NONE);
+        CF_HIP(h, run_conv(h, m2, B, st));
+        if (hd == 0) {
+            float* delta = hist ? hist + (long)B * 2 * Hp * Wp : h->idDelta;
+            CF_HIP(h, launch_convex_upsample(h->idDflow, 1, h->maskbuf, 576, B, h8, w8, delta, flow_final, h->H, h->W, h->padH,
+                                             h->padW, flag, flow_init, hist, st));
+        } else {
+            CF_HIP(h, launch_convex_upsample(h->idDflow, 1, h->maskbuf, 576, B, h8, w8, next_flow, nullptr, h->H, h->W, h->padH,
+                                             h->padW, nullptr, nullptr, nullptr, st));
+        }
+    }
+    return CF_OK;
+}
+
 extern "C" int cf_flow_forward(cf_handle* h, const float* in0, const float* in1, const float* flow_init, float* flow_final,
                                float* flow_low, float* flow_preds, void* stream) {
     if (!h) return CF_ERR_ARG;
     if (!h->finalized || !h->has_flow) return h->fail(CF_ERR_STATE, "cf_flow_forward: flow-net weights not finalised");
-    if (h->cfg.mode != CF_MODE_EIFLOW && h->cfg.mode != CF_MODE_ERAFT) return h->fail(CF_ERR_UNSUPPORTED, "cf_flow_forward: handle has no flow network");
-    if (!in0 || !in1 || !flow_final) return h->fail(CF_ERR_ARG, "cf_flow_forward: null pointer");
+    if (h->cfg.mode == CF_MODE_CISTA) return h->fail(CF_ERR_UNSUPPORTED, "cf_flow_forward: handle has no flow network");
+    if (!in0 || !flow_final) return h->fail(CF_ERR_ARG, "cf_flow_forward: null pointer");
     CF_HIP(h, hipSetDevice(h->cfg.device));
+    if (h->cfg.mode == CF_MODE_IDNET)   // flow_low = next_flow (padded), flow_preds = {flow_total, delta_flow}
+        return idnet_forward(h, in0, flow_init, flow_final, flow_low, flow_preds, h->flag, static_cast<hipStream_t>(stream));
+    if (!in1) return h->fail(CF_ERR_ARG, "cf_flow_forward: null pointer");
     return eiflow_forward(h, in0, in1, flow_init, flow_final, flow_low, flow_preds, h->flag, static_cast<hipStream_t>(stream));
 }
 
@@ -987,7 +1132,8 @@ extern "C" int cf_step(cf_handle* h, const float* in0, const float* in1, const f
                        float* z_warped_out, float* c_out, float* z_out, float* h_out, float* cc_out, void* stream) {
     if (!h) return CF_ERR_ARG;
     if (!h->finalized || !h->has_cista || !h->has_flow) return h->fail(CF_ERR_STATE, "cf_step: weights not finalised");
-    if (h->cfg.mode != CF_MODE_EIFLOW && h->cfg.mode != CF_MODE_ERAFT) return h->fail(CF_ERR_UNSUPPORTED, "cf_step: mode not built yet");
+    if (h->cfg.mode == CF_MODE_CISTA) return h->fail(CF_ERR_UNSUPPORTED, "cf_step: handle has no flow network");
+    if (h->cfg.mode == CF_MODE_IDNET && !in1) in1 = in0;
     if (!in0 || !in1 || !rec_img0 || !I_out || !flow_final || !c_out || !z_out || !h_out || !cc_out)
         return h->fail(CF_ERR_ARG, "cf_step: null pointer");
     if ((h_prev == nullptr) != (cc_prev == nullptr)) return h->fail(CF_ERR_ARG, "cf_step: h_prev/cc_prev must come together");
@@ -995,7 +1141,11 @@ extern "C" int cf_step(cf_handle* h, const float* in0, const float* in1, const f
     CF_HIP(h, hipSetDevice(h->cfg.device));
     int rc;
     // flow estimation from E_0^1 and the previous reconstruction (e2v_model.py:170-174)
-    if ((rc = eiflow_forward(h, in0, in1, flow_init, flow_final, flow_low, flow_preds, h->flag, st))) return rc;
+    if (h->cfg.mode == CF_MODE_IDNET) {
+        if ((rc = idnet_forward(h, in0, flow_init, flow_final, flow_low, flow_preds, h->flag, st))) return rc;
+    } else if ((rc = eiflow_forward(h, in0, in1, flow_init, flow_final, flow_low, flow_preds, h->flag, st))) {
+        return rc;
+    }
     const float* flow = flow_final;
     if (gt_flow) {   // e2v_model.py:181-182
         flow = gt_flow;
@@ -1048,7 +1198,7 @@ static int op_conv2d_impl(const float* in, int B, int Cin, int H, int W, const f
     pc.bias = static_cast<float*>(bb.p);
     if (hipMemsetAsync(pc.w, 0, (size_t)pc.rows * pc.Ktot * sizeof(float), st) != hipSuccess) return CF_ERR_HIP;
     if (hipMemsetAsync(pc.bias, 0, pc.rows * sizeof(float), st) != hipSuccess) return CF_ERR_HIP;
-    if (launch_pack_weight(weight, pc.w, Cout, Cin, KH, KW, pc.cin_pad, pc.Ktot, 0, gather ? 1 : 0, 0, 0, 0, nullptr, nullptr, nullptr,
+    if (launch_pack_weight(weight, pc.w, Cout, Cin, KH, KW, pc.cin_pad, pc.Ktot, 0, gather ? 1 : 0, 0, 0, 0, 0, nullptr, nullptr, nullptr,
                            nullptr, 0.f, bias, pc.bias, st) != hipSuccess)
         return CF_ERR_HIP;
     ConvParams p;

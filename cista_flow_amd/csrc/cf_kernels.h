@@ -94,9 +94,11 @@ const char* conv_tile_name(int tile);
 // src: OIHW [Cout][Cin][KH][KW]  ->  dst rows [row0 .. row0+Cout) of [rows][Ktot]
 //   gather==0: k = tap*cin_pad + c ; gather==1: k = tap*Cin + c
 // optional BatchNorm fold (eval): w' = w*g/sqrt(var+eps), b' = (b-mean)*g/sqrt(var+eps)+beta
-// c_begin/c_count select an input-channel slice of src (c_count <= 0: all), written at channel dst_coff.
+// c_begin/c_count select an input-channel slice of src (c_count <= 0: all), written at channel dst_coff;
+// accum != 0 adds to what is already packed (sums input channels that always carry identical data).
 hipError_t launch_pack_weight(const float* src, float* dst, int Cout, int Cin, int KH, int KW,
                               int cin_pad, int Ktot, int row0, int gather, int c_begin, int c_count, int dst_coff,
+                              int accum,
                               const float* bn_w, const float* bn_b, const float* bn_mean,
                               const float* bn_var, float bn_eps,
                               const float* bias_src, float* bias_dst, hipStream_t s);
@@ -155,9 +157,16 @@ hipError_t launch_upflow(const float* coords1, int B, int h8, int w8, int ds, fl
 // mask [B][N][576] (channel k*64 + i*8 + j) applied to unfold(8 * flow, 3x3, pad 1); flow = coords1 - coords0
 // when `coords_is_flow == 0`, else `coords1` already holds the flow.  Writes the padded flow_up (nullable) and
 // the un-padded flow_final (nullable), raises `flag` on any non-zero flow_final value.
+// add (nullable, padded [B][2][8h8][8w8]): flow_final / total_out receive add + up (IDNet: flow_init + delta).
 hipError_t launch_convex_upsample(const float* coords1, int coords_is_flow, const float* mask, int mask_ld, int B,
                                   int h8, int w8, float* flow_up, float* flow_final, int H, int W, int padH,
-                                  int padW, int* flag, hipStream_t s);
+                                  int padW, int* flag, const float* add, float* total_out, hipStream_t s);
+
+// IDNet deblur (idn/idedeq.py:74-92): out[b][t] = grid_sample(bins[b][t], p + flow*t/(T-1)) with the grid
+// normalised by (W-1) but align_corners=False and zero padding (sampled pixel x*W/(W-1) - 0.5: not an identity
+// at zero flow).  bins: un-padded [B][T][H][W]; flow (nullable = 0): padded [B][2][Hp][Wp]; out: [B][T][Hp][Wp].
+hipError_t launch_idn_deblur(const float* bins, const float* flow, float* out, int B, int T, int H, int W, int padH,
+                             int padW, hipStream_t s);
 
 // layout helpers for the Python boundary / tests
 hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int dst_ld, int B, int C, int HW, hipStream_t s);

@@ -718,7 +718,7 @@ hipError_t launch_conv(const ConvParams& p, int batch, hipStream_t s, int tile, 
 // ---------------------------------------------------------------------------
 __global__ void pack_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int Cin,
                                    int KH, int KW, int cin_pad, int Ktot, int row0, int gather, int c_begin,
-                                   int c_count, int dst_coff, const float* bn_w, const float* bn_b,
+                                   int c_count, int dst_coff, int accum, const float* bn_w, const float* bn_b,
                                    const float* bn_mean, const float* bn_var, float bn_eps, const float* bias_src,
                                    float* bias_dst) {
     const long total = (long)Cout * c_count * KH * KW;
@@ -734,7 +734,8 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, float* __restr
         if (bn_var) v *= bn_w[o] / sqrtf(bn_var[o] + bn_eps);
         const int tap = kh * KW + kw;
         const long k = gather ? ((long)tap * c_count + c) : ((long)tap * cin_pad + dst_coff + c);
-        dst[(long)(row0 + o) * Ktot + k] = v;
+        float* d = dst + (long)(row0 + o) * Ktot + k;
+        *d = accum ? (*d + v) : v;
     }
     if (idx < Cout && bias_dst) {
         const int o = (int)idx;
@@ -745,21 +746,21 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, float* __restr
 }
 
 hipError_t launch_pack_weight(const float* src, float* dst, int Cout, int Cin, int KH, int KW, int cin_pad,
-                              int Ktot, int row0, int gather, int c_begin, int c_count, int dst_coff,
+                              int Ktot, int row0, int gather, int c_begin, int c_count, int dst_coff, int accum,
                               const float* bn_w, const float* bn_b, const float* bn_mean, const float* bn_var,
                               float bn_eps, const float* bias_src, float* bias_dst, hipStream_t s) {
     if (c_count <= 0) { c_begin = 0; c_count = Cin; }
     const long total = (long)Cout * c_count * KH * KW;
     if (total <= 0 || c_begin < 0 || c_begin + c_count > Cin || dst_coff < 0) return hipErrorInvalidValue;
     if (gather) {
-        if (Ktot < KH * KW * c_count || c_begin != 0 || dst_coff != 0) return hipErrorInvalidValue;
+        if (Ktot < KH * KW * c_count || dst_coff != 0) return hipErrorInvalidValue;
     } else {
         if (cin_pad < dst_coff + c_count || Ktot != KH * KW * cin_pad) return hipErrorInvalidValue;
     }
     const int threads = 256;
     const long blocks = (total + threads - 1) / threads;
     hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)blocks), dim3(threads), 0, s, src, dst, Cout, Cin, KH, KW,
-                       cin_pad, Ktot, row0, gather, c_begin, c_count, dst_coff, bn_w, bn_b, bn_mean, bn_var, bn_eps,
+                       cin_pad, Ktot, row0, gather, c_begin, c_count, dst_coff, accum, bn_w, bn_b, bn_mean, bn_var, bn_eps,
                        bias_src, bias_dst);
     return hipGetLastError();
 }

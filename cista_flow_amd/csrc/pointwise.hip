@@ -508,7 +508,8 @@ hipError_t launch_upflow(const float* coords1, int B, int h8, int w8, int ds, fl
 __global__ __launch_bounds__(256) void convex_upsample_kernel(const float* __restrict__ coords1, int coords_is_flow,
                                                               const float* __restrict__ mask, int mask_ld, int B, int h8,
                                                               int w8, float* flow_up, float* flow_final, int H, int W,
-                                                              int padH, int padW, int* flag) {
+                                                              int padH, int padW, int* flag, const float* add,
+                                                              float* total_out) {
     const int lane = threadIdx.x & 63;
     const long N = (long)h8 * w8;
     const long qid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -553,14 +554,25 @@ __global__ __launch_bounds__(256) void convex_upsample_kernel(const float* __res
         const int i = lane >> 3, j = lane & 7;
         const int oy = 8 * y + i, ox = 8 * x + j;
         const int Hp = 8 * h8, Wp = 8 * w8;
+        const long o0 = (((long)b * 2 + 0) * Hp + oy) * Wp + ox;
+        const long o1 = (((long)b * 2 + 1) * Hp + oy) * Wp + ox;
         if (flow_up) {
-            flow_up[(((long)b * 2 + 0) * Hp + oy) * Wp + ox] = ux;
-            flow_up[(((long)b * 2 + 1) * Hp + oy) * Wp + ox] = uy;
+            flow_up[o0] = ux;
+            flow_up[o1] = uy;
+        }
+        float tx = ux, ty = uy;
+        if (add) {     // flow_total = flow_total + delta_flow (idedeq.py:206-207)
+            tx = add[o0] + ux;
+            ty = add[o1] + uy;
+        }
+        if (total_out) {
+            total_out[o0] = tx;
+            total_out[o1] = ty;
         }
         if (flow_final && oy >= padH && ox >= padW) {
-            flow_final[(((long)b * 2 + 0) * H + (oy - padH)) * W + (ox - padW)] = ux;
-            flow_final[(((long)b * 2 + 1) * H + (oy - padH)) * W + (ox - padW)] = uy;
-            nz = (ux != 0.0f) || (uy != 0.0f);
+            flow_final[(((long)b * 2 + 0) * H + (oy - padH)) * W + (ox - padW)] = tx;
+            flow_final[(((long)b * 2 + 1) * H + (oy - padH)) * W + (ox - padW)] = ty;
+            nz = (tx != 0.0f) || (ty != 0.0f);
         }
     }
     if (flag && __any(nz)) {
@@ -570,12 +582,61 @@ __global__ __launch_bounds__(256) void convex_upsample_kernel(const float* __res
 
 hipError_t launch_convex_upsample(const float* coords1, int coords_is_flow, const float* mask, int mask_ld, int B, int h8,
                                   int w8, float* flow_up, float* flow_final, int H, int W, int padH, int padW, int* flag,
-                                  hipStream_t s) {
+                                  const float* add, float* total_out, hipStream_t s) {
     if (!coords1 || !mask || mask_ld < 576 || B <= 0 || h8 <= 0 || w8 <= 0) return hipErrorInvalidValue;
     if (flow_final && (H + padH != h8 * 8 || W + padW != w8 * 8)) return hipErrorInvalidValue;
     const long nq = (long)B * h8 * w8;
     hipLaunchKernelGGL(convex_upsample_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, coords1, coords_is_flow,
-                       mask, mask_ld, B, h8, w8, flow_up, flow_final, H, W, padH, padW, flag);
+                       mask, mask_ld, B, h8, w8, flow_up, flow_final, H, W, padH, padW, flag, add, total_out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// IDNet deblur: per-bin bilinear gather along the flow (zeros padding, align_corners=False on a (W-1)-normalised
+// grid -- ATen CPU: ix = (g + 1) * (W / 2) - 0.5)
+// ---------------------------------------------------------------------------
+__global__ void idn_deblur_kernel(const float* __restrict__ bins, const float* __restrict__ flow, float* __restrict__ out,
+                                  int B, int T, int H, int W, int padH, int padW) {
+    const int Hp = H + padH, Wp = W + padW;
+    const long total = (long)B * T * Hp * Wp;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int x = (int)(gid % Wp);
+    const int y = (int)((gid / Wp) % Hp);
+    const int t = (int)((gid / ((long)Wp * Hp)) % T);
+    const int b = (int)(gid / ((long)Wp * Hp * T));
+    float fx = 0.f, fy = 0.f;
+    if (flow) {
+        fx = flow[(((long)b * 2 + 0) * Hp + y) * Wp + x];
+        fy = flow[(((long)b * 2 + 1) * Hp + y) * Wp + x];
+    }
+    const float dx = fx * (float)t / (float)(T - 1);
+    const float dy = fy * (float)t / (float)(T - 1);
+    const float gx = ((float)x + dx) / (float)(Wp - 1) * 2.f - 1.f;
+    const float gy = ((float)y + dy) / (float)(Hp - 1) * 2.f - 1.f;
+    const float ix = (gx + 1.f) * ((float)Wp / 2.f) - 0.5f;
+    const float iy = (gy + 1.f) * ((float)Hp / 2.f) - 0.5f;
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float tx = ix - x0f, ty = iy - y0f;
+    const float* src = bins + ((long)b * T + t) * H * W;
+    // the source is ImagePadder-padded: padded pixel (py,px) = bins[py-padH][px-padW], zero in the pad
+    auto tap = [&](float yf, float xf) -> float {
+        if (!(yf >= 0.f && yf <= (float)(Hp - 1) && xf >= 0.f && xf <= (float)(Wp - 1))) return 0.f;
+        const int py = (int)yf - padH, px = (int)xf - padW;
+        if (py < 0 || px < 0) return 0.f;
+        return src[(long)py * W + px];
+    };
+    const float v = tap(y0f, x0f) * ((1.f - tx) * (1.f - ty)) + tap(y0f, x0f + 1.f) * (tx * (1.f - ty)) +
+                    tap(y0f + 1.f, x0f) * ((1.f - tx) * ty) + tap(y0f + 1.f, x0f + 1.f) * (tx * ty);
+    out[gid] = v;
+}
+
+hipError_t launch_idn_deblur(const float* bins, const float* flow, float* out, int B, int T, int H, int W, int padH,
+                             int padW, hipStream_t s) {
+    if (!bins || !out || B <= 0 || T < 2 || H <= 1 || W <= 1) return hipErrorInvalidValue;
+    const long total = (long)B * T * (H + padH) * (W + padW);
+    hipLaunchKernelGGL(idn_deblur_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, bins, flow, out, B, T, H, W,
+                       padH, padW);
     return hipGetLastError();
 }
 

@@ -19,6 +19,7 @@ from ..runtime import HipBackend, empty_nhwc, nhwc_state
 from ..utils.flow_utils import FrameWarp
 from ..DCEIFlow.DCEIFlow import DCEIFlow
 from ..ERAFT.eraft import ERAFT
+from ..idn.idedeq import IDEDEQIDO
 from .base_layers import *   # noqa: F401,F403  (the reference re-exports the layer library the same way)
 from .base_layers import ConvLayer, ConvLSTC, IstaBlock, RecurrentConvLayer, UpsampleConvLayer
 
@@ -204,3 +205,59 @@ class ERAFTCistaNet(_HipFlowRec):
         _lib.check_f32_cuda(ev, "event_voxel", (B, self.num_bins, H, W))
         _lib.check_f32_cuda(rec0, "rec_img0", (B, 1, H, W))
         return self._step(ev_old, ev, rec0, states, None, batch_gt.get('gt_flow'))
+
+
+class IDCistaNet(_HipFlowRec):
+    '''CISTA-Flow: CISTA-LSTC + IDNet  (e2v_model.py:252-308)'''
+    _mode = _lib.CF_MODE_IDNET
+
+    def __init__(self, args):
+        super(IDCistaNet, self).__init__(args)
+        from types import SimpleNamespace
+        # the reference builds this with OmegaConf.create; IDEDEQIDO only reads it through getattr
+        config = SimpleNamespace(update_iters=1, pred_next_flow=True, image_dim=args.image_dim, num_bins=args.num_bins)
+        self.event_flownet = IDEDEQIDO(config)
+        self.flow_iters = 1
+        self._backend = None
+
+    def forward(self, batch_data, states, flow_init=None, batch_gt=dict([])):
+        '''batch_data: event_voxel [B,bins,H,W], rec_img0 [B,1,H,W]; flow_init: padded [B,2,Hp,Wp] = the previous
+        frame's batch_flow['next_flow'] (test_with_flow.py:151-154) or None.'''
+        ev = batch_data['event_voxel']
+        rec0 = batch_data['rec_img0']
+        gt_flow = batch_gt.get('gt_flow')
+        H, W = self.image_dim
+        B = ev.shape[0]
+        _lib.check_f32_cuda(ev, "event_voxel", (B, self.num_bins, H, W))
+        _lib.check_f32_cuda(rec0, "rec_img0", (B, 1, H, W))
+        fnet = self.event_flownet
+        Hp, Wp = fnet.image_padder.padded_size()
+        if flow_init is not None:
+            _lib.check_f32_cuda(flow_init, "flow_init", (B, 2, Hp, Wp))
+            flow_init = flow_init.contiguous()
+        if gt_flow is not None:
+            _lib.check_f32_cuda(gt_flow, "gt_flow", (B, 2, H, W))
+            gt_flow = gt_flow.contiguous()
+        dev = ev.device
+        cn = self.cista_net
+        c_prev, z_prev, h_prev, cc_prev = cn.unpack_states(states, B)
+        s2, s1 = cn.state_shapes(B)
+        I = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
+        flow_final = torch.empty((B, 2, H, W), dtype=torch.float32, device=dev)
+        next_flow = torch.empty((B, 2, Hp, Wp), dtype=torch.float32, device=dev)
+        hist = torch.empty((2, B, 2, Hp, Wp), dtype=torch.float32, device=dev)
+        z_warp = empty_nhwc(*s2, dev) if z_prev is not None else None
+        c, z = empty_nhwc(*s2, dev), empty_nhwc(*s2, dev)
+        hh, cc = empty_nhwc(*s1, dev), empty_nhwc(*s1, dev)
+        h = self._be().get(B, dev)
+        p = _lib.ptr
+        evc = ev.contiguous()
+        h.check(h.lib.cf_step(h.h, p(evc), p(evc), p(rec0.contiguous()), p(flow_init), p(gt_flow), p(c_prev), p(z_prev),
+                              p(h_prev), p(cc_prev), p(I), p(flow_final), p(next_flow), p(hist), p(z_warp), p(c), p(z),
+                              p(hh), p(cc), _lib.current_stream_ptr()), "cf_step")
+        if z_warp is not None:
+            states[1] = z_warp
+        d0 = flow_init if flow_init is not None else torch.zeros_like(hist[1])
+        batch_flow = {'flow_final': flow_final, 'next_flow': next_flow, 'delta_flow': torch.stack([d0, hist[1]], 1),
+                      'flow_preds': [hist[0]]}
+        return I, batch_flow, [c, z, (hh, cc)]

@@ -460,3 +460,107 @@ def eraft_step(sd, batch_data, states, warp_mode="forward", depth=5, iters=12, g
             states[1] = warp(states[1], dflow, warp_mode)
     I_rec, new_states = cista_forward(sd, batch_data["event_voxel"], warped_I, states, depth=depth)
     return I_rec, bf, new_states
+
+
+# ----------------------------------------------------------------------------------------------
+# IDNet  (a15)   /root/reference/idn/idedeq.py:48-61,74-92,124-227 ; idn/extractor.py:63-125 ;
+#                idn/update.py:29-85 ; e2v/e2v_model.py:252-308
+# ----------------------------------------------------------------------------------------------
+
+
+def idn_deblur(x, flow):
+    """deblur_tensor (voxel mode): bin t sampled at p + flow*t/(T-1); grid normalised with (W-1) but
+    grid_sample(align_corners=False, zeros) -> pixel x*W/(W-1) - 0.5 (zero flow is not an identity)."""
+    B, T, H, W = x.shape
+    gy, gx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    out = torch.zeros_like(x)
+    for t in range(T):
+        dp = flow * t / (T - 1)
+        sx = (gx[None].float() + dp[:, 0]) / (W - 1) * 2 - 1
+        sy = (gy[None].float() + dp[:, 1]) / (H - 1) * 2 - 1
+        ix = (sx + 1) * (W / 2) - 0.5
+        iy = (sy + 1) * (H / 2) - 0.5
+        x0, y0 = ix.floor(), iy.floor()
+        tx, ty = ix - x0, iy - y0
+        x0, y0 = x0.long(), y0.long()
+        flat = x[:, t].reshape(B, H * W)
+
+        def tap(yy, xx):
+            ok = ((xx >= 0) & (xx < W) & (yy >= 0) & (yy < H)).float()
+            idx = (yy.clamp(0, H - 1) * W + xx.clamp(0, W - 1)).reshape(B, H * W)
+            return flat.gather(1, idx).reshape(B, H, W) * ok
+
+        out[:, t] = tap(y0, x0) * ((1 - tx) * (1 - ty)) + tap(y0, x0 + 1) * (tx * (1 - ty)) \
+            + tap(y0 + 1, x0) * ((1 - tx) * ty) + tap(y0 + 1, x0 + 1) * (tx * ty)
+    return out
+
+
+def lite_encoder(sd, pre, x):
+    """LiteEncoder(stride=2): conv 7x7 s2 + relu, two stages of norm-free residual blocks (s2 each)."""
+
+    def c(name, t, stride, pad):
+        return conv2d(t, sd[name + ".weight"], sd[name + ".bias"], stride, (pad, pad))
+
+    x = torch.relu(c(pre + ".conv1", x, 2, 3))
+    for L in (1, 2):
+        for blk in range(2):
+            k = "%s.layer%d.%d" % (pre, L, blk)
+            stride = 2 if blk == 0 else 1
+            y = torch.relu(c(k + ".conv1", x, stride, 1))
+            y = torch.relu(c(k + ".conv2", y, 1, 1))
+            if stride != 1:
+                x = c(k + ".downsample.0", x, stride, 0)
+            x = torch.relu(x + y)
+    return x
+
+
+def idnet_forward(sd, event_bins, flow_init=None, prefix="event_flownet."):
+    """IDEDEQIDO.forward with update_iters=1, pred_next_flow=True."""
+    p = prefix
+    B, T, H, W = event_bins.shape
+    x_raw, ph, pw = image_pad(event_bins, H, W)
+    Hp, Wp = x_raw.shape[-2:]
+    flow_total = torch.zeros(B, 2, Hp, Wp) if flow_init is None else flow_init.clone()
+    delta0 = flow_total
+    x_deblur = idn_deblur(x_raw, flow_total)
+    net = torch.zeros(B, 96, Hp // 8, Wp // 8)
+    u = p + "update_net."
+
+    def c(name, t, pad):
+        return conv2d(t, sd[name + ".weight"], sd[name + ".bias"], 1, (pad, pad))
+
+    for t in range(T):
+        sl = torch.stack([x_deblur[:, t], x_deblur[:, t]], dim=1)       # the two input channels are identical
+        f = lite_encoder(sd, p + "fnet", sl)
+        hx = torch.cat([net, f], 1)
+        z = torch.sigmoid(c(u + "gru.convz", hx, 1))
+        r = torch.sigmoid(c(u + "gru.convr", hx, 1))
+        q = torch.tanh(c(u + "gru.convq", torch.cat([r * net, f], 1), 1))
+        net = (1 - z) * net + z * q
+
+    def head(fh, mk):
+        d = c(u + fh + ".conv2", torch.relu(c(u + fh + ".conv1", net, 1)), 1)
+        m = c(u + mk + ".2", torch.relu(c(u + mk + ".0", net, 1)), 0)
+        return convex_upsample(d, m)
+
+    delta = head("flow_head", "mask")
+    next_flow = head("flow_head2", "mask2")
+    flow_total = flow_total + delta
+    return dict(flow_final=flow_total[..., ph:, pw:], next_flow=next_flow, delta_flow=torch.stack([delta0, delta], 1),
+                flow_preds=[flow_total])
+
+
+def idnet_step(sd, batch_data, states, flow_init=None, warp_mode="forward", depth=5, gt_flow=None):
+    """IDCistaNet.forward."""
+    bf = idnet_forward(sd, batch_data["event_voxel"], flow_init)
+    flow_final = bf["flow_final"] if gt_flow is None else gt_flow
+    if not flow_final.any():
+        warped_I = batch_data["rec_img0"]
+    else:
+        warped_I = warp(batch_data["rec_img0"], flow_final, warp_mode)
+        if states is not None:
+            H, W = flow_final.shape[-2:]
+            dflow = interp_bilinear(flow_final, H // 2, W // 2, align_corners=True)
+            states[1] = warp(states[1], dflow, warp_mode)
+    I_rec, new_states = cista_forward(sd, batch_data["event_voxel"], warped_I, states, depth=depth)
+    return I_rec, bf, new_states

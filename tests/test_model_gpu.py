@@ -123,6 +123,32 @@ def test_eraft_golden_sequence(gpu):
             prev = I.clone()
 
 
+@pytest.mark.parametrize("name", ["idnet_68x92.npz", "idnet_260x346.npz"])
+def test_idnet_golden_sequence(gpu, name):
+    """cista-idnet (BASELINE configs[4] geometry 260x346) with the driver's next_flow -> flow_init carry."""
+    from cista_flow_amd.e2v.e2v_model import IDCistaNet
+    g = gu.load(name)
+    H, W, B, frames, seed = [int(v) for v in g["meta"]]
+    m = IDCistaNet(args_for(H, W)).eval()
+    wu.fill_module(m, seed)
+    m = m.to(gpu)
+    states, prev, flow_init = None, torch.zeros(B, 1, H, W, device=gpu), None
+    with torch.no_grad():
+        for t in range(frames):
+            ev = torch.from_numpy(g["ev_%d" % t]).to(gpu)
+            I, bf, states = m({"event_voxel": ev, "rec_img0": prev}, states, flow_init, {})
+            flow_init = bf["next_flow"]
+            assert gu.rel_err(bf["flow_final"].cpu(), g["flow_%d" % t]) < TOL, t
+            st = 3 if H >= 200 else 1
+            assert gu.rel_err(bf["next_flow"].cpu()[..., ::st, ::st], g["next_%d" % t]) < TOL, t
+            assert gu.rel_err(bf["delta_flow"][:, 1].cpu()[..., ::st, ::st], g["delta_%d" % t]) < TOL, t
+            assert gu.rel_err(I.cpu(), g["I_%d" % t]) < TOL, t
+            assert gu.rel_err(gu.sub(states[0].cpu()), g["c_%d" % t]) < TOL, t
+            assert gu.rel_err(gu.sub(states[1].cpu()), g["z_%d" % t]) < TOL, t
+            assert gu.rel_err(gu.sub(states[2][0].cpu()), g["h_%d" % t]) < TOL, t
+            prev = I.clone()
+
+
 def test_eraft_last_only_matches_full(gpu):
     """return_flow_preds=False skips the 11 dead mask-head / up-sampling evaluations; flow_final is unchanged."""
     from cista_flow_amd.ERAFT.eraft import ERAFT

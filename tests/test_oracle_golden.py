@@ -94,10 +94,29 @@ def test_eraft_golden():
         prev = I.clone()
 
 
+@pytest.mark.parametrize("name", ["idnet_68x92.npz", "idnet_260x346.npz"])
+def test_idnet_golden(name):
+    g = gu.load(name)
+    H, W, B, frames, seed = [int(v) for v in g["meta"]]
+    sd = wu.make_state_dict(gu.layout("idnet_state_dict_layout.json"), seed)
+    states, prev, flow_init = None, torch.zeros(B, 1, H, W), None
+    for t in range(frames):
+        ev = torch.from_numpy(g["ev_%d" % t])
+        I, bf, states = orc.idnet_step(sd, {"event_voxel": ev, "rec_img0": prev}, states, flow_init)
+        flow_init = bf["next_flow"]
+        assert gu.rel_err(bf["flow_final"], g["flow_%d" % t]) < 5e-5, t
+        st = 3 if H >= 200 else 1
+        assert gu.rel_err(bf["next_flow"][..., ::st, ::st], g["next_%d" % t]) < 5e-5, t
+        assert gu.rel_err(bf["delta_flow"][:, 1][..., ::st, ::st], g["delta_%d" % t]) < 5e-5, t
+        assert gu.rel_err(I, g["I_%d" % t]) < 5e-5, t
+        assert gu.rel_err(gu.sub(states[1]), g["z_%d" % t]) < 5e-5, t
+        prev = I.clone()
+
+
 def test_state_dict_layout_matches_reference():
     """The shell modules must expose the reference's state_dict keys, shapes and order (262 entries)."""
     import argparse
-    from cista_flow_amd.e2v.e2v_model import CistaLSTCNet, DCEIFlowCistaNet, ERAFTCistaNet
+    from cista_flow_amd.e2v.e2v_model import CistaLSTCNet, DCEIFlowCistaNet, ERAFTCistaNet, IDCistaNet
     a = argparse.Namespace(image_dim=[180, 240], num_bins=5, warp_mode='forward', base_channels=64, depth=5, ds=8, is_bi=False)
     m = DCEIFlowCistaNet(a)
     assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == gu.layout("eiflow_state_dict_layout.json")
@@ -105,6 +124,8 @@ def test_state_dict_layout_matches_reference():
     assert [(k, tuple(v.shape)) for k, v in c.state_dict().items()] == gu.layout("cista_state_dict_layout.json")
     e = ERAFTCistaNet(a)
     assert [(k, tuple(v.shape)) for k, v in e.state_dict().items()] == gu.layout("eraft_state_dict_layout.json")
+    d = IDCistaNet(a)
+    assert [(k, tuple(v.shape)) for k, v in d.state_dict().items()] == gu.layout("idnet_state_dict_layout.json")
     # the five lista blocks alias one storage and survive a strict load
     sd = wu.make_state_dict(gu.layout("eiflow_state_dict_layout.json"), 5)
     m.load_state_dict(sd, strict=True)

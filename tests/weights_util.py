@@ -43,14 +43,16 @@ def make_tensor(key, shape, seed):
             gain = 6.0
         elif "flow_head.conv2" in ck:
             gain = 0.08
-        elif "update_block.mask.2" in ck:
+        elif "flow_head2.conv2" in ck:
+            gain = 0.08
+        elif "update_block.mask.2" in ck or "update_net.mask.2" in ck or "update_net.mask2.2" in ck:
             gain = 3.0       # spread the convex-upsampling logits so the softmax is not uniform
-        elif ck.startswith("cista_net") or not ("fnet" in ck or "cnet" in ck or "enet" in ck or "update_block" in ck or "fusion" in ck):
+        elif ck.startswith("cista_net") or not ("fnet" in ck or "cnet" in ck or "enet" in ck or "update_block" in ck or "update_net" in ck or "fusion" in ck):
             gain = 1.5
         else:
             gain = 1.0
         a = rng.normal(0.0, gain / np.sqrt(fan_in), shape)
-    elif ck.endswith("flow_head.conv2.bias"):
+    elif ck.endswith("flow_head.conv2.bias") or ck.endswith("flow_head2.conv2.bias"):
         a = rng.normal(0.0, 0.008, shape)
     elif ck.endswith(".weight"):      # BatchNorm scale
         a = rng.uniform(0.5, 1.5, shape)

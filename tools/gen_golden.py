@@ -115,6 +115,35 @@ def run_eraft(ref_model, H, W, B, frames, seed, name):
     print(name)
 
 
+def run_idnet(ref_model, H, W, B, frames, seed, name):
+    """driver loop of test_with_flow.py:150-154: flow_init = previous batch_flow['next_flow'] (padded)."""
+    from weights_util import fill_module, synth_events
+    torch.manual_seed(0)
+    model = ref_model.IDCistaNet(ns(H, W)).eval()
+    fill_module(model, seed)
+    out = {"meta": np.array([H, W, B, frames, seed], dtype=np.int64)}
+    states = None
+    prev = torch.zeros(B, 1, H, W)
+    flow_init = None
+    with torch.no_grad():
+        for t in range(frames):
+            ev = synth_events(B, 5, H, W, seed * 1000 + t)
+            I, bf, states = model({"event_voxel": ev, "rec_img0": prev}, states, flow_init, {})
+            flow_init = bf["next_flow"]
+            out["ev_%d" % t] = ev.numpy()
+            out["I_%d" % t] = I.numpy()
+            out["flow_%d" % t] = bf["flow_final"].numpy()
+            st = 3 if H >= 200 else 1          # keep the large fixture small: strided probes of the padded flows
+            out["next_%d" % t] = bf["next_flow"][..., ::st, ::st].contiguous().numpy()
+            out["delta_%d" % t] = bf["delta_flow"][:, 1][..., ::st, ::st].contiguous().numpy()
+            out["c_%d" % t] = sub(states[0])
+            out["z_%d" % t] = sub(states[1])
+            out["h_%d" % t] = sub(states[2][0])
+            prev = I.clone()
+    np.savez_compressed(os.path.join(GOLD, name), **out)
+    print(name)
+
+
 def run_cista(ref_model, H, W, B, frames, seed, name):
     from weights_util import fill_module, synth_events
     torch.manual_seed(0)
@@ -168,9 +197,15 @@ def main():
     e = ref_model.ERAFTCistaNet(ns(180, 240))
     with open(os.path.join(GOLD, "eraft_state_dict_layout.json"), "w") as f:
         json.dump([[k, list(v.shape)] for k, v in e.state_dict().items()], f)
+    d = ref_model.IDCistaNet(ns(180, 240))
+    with open(os.path.join(GOLD, "idnet_state_dict_layout.json"), "w") as f:
+        json.dump([[k, list(v.shape)] for k, v in d.state_dict().items()], f)
     if "--only-new" in sys.argv:
-        run_eraft(ref_model, 100, 124, 2, 3, 31, "eraft_100x124.npz")
+        run_idnet(ref_model, 68, 92, 2, 3, 41, "idnet_68x92.npz")
+        run_idnet(ref_model, 260, 346, 1, 2, 42, "idnet_260x346.npz")
         return
+    run_idnet(ref_model, 68, 92, 2, 3, 41, "idnet_68x92.npz")
+    run_idnet(ref_model, 260, 346, 1, 2, 42, "idnet_260x346.npz")
     run_eraft(ref_model, 100, 124, 2, 3, 31, "eraft_100x124.npz")
     run_warp(ref_flow, "warp.npz")
     run_cista(ref_model, 36, 52, 2, 3, 11, "cista_36x52.npz")
