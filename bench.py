@@ -177,7 +177,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom["name"])
+                traffic = json.load(open(tpath)).get(dom["name"], {}).get("bytes_per_launch")
             except Exception:
                 traffic = None
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12

@@ -248,6 +248,7 @@ ConvParams base_params() {
     memset(&p, 0, sizeof(p));
     p.out_cs = 1;
     p.aux0_cs = 1;
+    p.sched = -1;
     p.g_scale = 1.f;
     p.scale = 1.f;
     return p;

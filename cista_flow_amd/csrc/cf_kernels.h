@@ -82,6 +82,7 @@ struct ConvParams {
     const float* addend; int addend_ld; long addend_bs;   // v += addend[b][m][n] before the epilogue op
     int  k_real;        // un-padded K (taps * Cin): algorithmic-flop bookkeeping only
     const char* tag;    // layer name for the profiler (host side only)
+    int  sched;         // workgroup->tile map: -1 default (env CF_SCHED, else 1), 0 m-fastest, 1 XCD-aware
 };
 
 // tile: 0 auto, else explicit (see conv_igemm.hip); tile_used (nullable) returns the choice

@@ -20,6 +20,8 @@
 //   `2*image-1` (DCEIFlow/DCEIFlow.py:146) fused into the small-Cin gather read.
 #include "cf_kernels.h"
 
+#include <cstdlib>
+
 namespace cf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -221,10 +223,34 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int wmn = wave % WMN;
     const int wm = wmn / WAVES_N;
     const int wn = wmn % WAVES_N;
-    const int b = blockIdx.z;
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
     const int M = p.Ho * p.Wo;
+    // ---- workgroup -> tile map.  1-D grid; hardware deals consecutive block ids round-robin over the 8 XCDs
+    // (ids b and b+8 share an XCD and its L2).  sched 1 hands every XCD one contiguous run of logical tiles
+    // ordered (image, m-tile, n-tile): the n-tiles of an m-tile (same A rows) and vertically adjacent m-tiles
+    // (shared halo rows) then hit in the same L2 instead of being re-fetched through the fabric.  Speed only --
+    // any placement computes the same tiles.
+    const int mt = (M + BM - 1) / BM;
+    const int nt = (p.cout + BN - 1) / BN;
+    int tile_id = blockIdx.x;
+    if (p.sched == 1) {
+        const int nwg = gridDim.x;
+        const int q8 = nwg >> 3, r8 = nwg & 7;
+        const int xcd = tile_id & 7;
+        tile_id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (tile_id >> 3);
+    }
+    int b, m0, n0;
+    if (p.sched == 1) {
+        const int ny = tile_id % nt;
+        const int rest = tile_id / nt;
+        n0 = ny * BN;
+        m0 = (rest % mt) * BM;
+        b = rest / mt;
+    } else {
+        m0 = (tile_id % mt) * BM;
+        const int rest = tile_id / mt;
+        n0 = (rest % nt) * BN;
+        b = rest / nt;
+    }
 
     // per-thread A slots (row, quad) -- fixed for the whole K loop
     int a_oy[A_IT], a_ox[A_IT], a_row[A_IT], a_q[A_IT];
@@ -520,7 +546,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 template <int BM, int BN, int WM, int WN, int WK>
 static hipError_t launch_t(const ConvParams& p, int batch, hipStream_t s) {
     const int M = p.Ho * p.Wo;
-    dim3 grid((M + BM - 1) / BM, (p.cout + BN - 1) / BN, batch);
+    dim3 grid(((M + BM - 1) / BM) * ((p.cout + BN - 1) / BN) * batch);
     if (p.a_mode == A_NHWC) {
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, WK, A_NHWC>), grid, dim3(256), 0, s, p);
     } else if constexpr (WK == 1) {
@@ -625,20 +651,31 @@ static hipError_t launch_smalln(const ConvParams& p, int batch, hipStream_t s) {
 
 const char* conv_tile_name(int tile) {
     switch (tile) {
-        case 1: return "conv_igemm_kernel<128,128,2,2>";
-        case 2: return "conv_igemm_kernel<128,64,2,2>";
-        case 3: return "conv_igemm_kernel<128,96,4,1>";
-        case 4: return "conv_igemm_kernel<64,64,2,2>";
-        case 5: return "conv_igemm_kernel<64,128,2,2>";
-        case 6: return "conv_igemm_kernel<128,32,4,1>";
+        case 1: return "conv_igemm_kernel<128,128,2,2,1>";
+        case 2: return "conv_igemm_kernel<128,64,2,2,1>";
+        case 3: return "conv_igemm_kernel<128,96,4,1,1>";
+        case 4: return "conv_igemm_kernel<64,64,2,2,1>";
+        case 5: return "conv_igemm_kernel<64,128,2,2,1>";
+        case 6: return "conv_igemm_kernel<128,32,4,1,1>";
         case 7: return "conv_smalln_kernel";
-        case 8: return "conv_igemm_kernel<32,32,1,1,k4>";
-        case 9: return "conv_igemm_kernel<32,64,1,2,k2>";
+        case 8: return "conv_igemm_kernel<32,32,1,1,4>";
+        case 9: return "conv_igemm_kernel<32,64,1,2,2>";
         default: return "?";
     }
 }
 
-hipError_t launch_conv(const ConvParams& p, int batch, hipStream_t s, int tile, int* tile_used) {
+static int default_sched() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("CF_SCHED");
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
+
+hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int tile, int* tile_used) {
+    ConvParams p = p_in;
+    if (p.sched < 0) p.sched = default_sched();
     // ---- host-side shape checks: a bad descriptor must never reach the GPU ----
     if (p.Ktot <= 0 || (p.Ktot % KC) != 0 || p.cout <= 0 || batch <= 0 || p.Ho <= 0 || p.Wo <= 0)
         return hipErrorInvalidValue;

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs as MI355X_MICROARCH.md prescribes) of
+bench.py into profiles/hbm_traffic.json: fabric bytes per launch for every kernel.
+
+gfx950 correction (guide, section HBM): FETCH_SIZE reports half the bytes of wide coalesced reads -> doubled;
+WRITE_SIZE is exact.  Both counters are in KiB and include Infinity-Cache hits (they count L2's fabric side).
+
+    python tools/collect_traffic.py <dir_with_FETCH_SIZE_pass> <dir_with_WRITE_SIZE_pass> profiles/hbm_traffic.json
+"""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+
+def per_kernel(d, counter):
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            n = r["Kernel_Name"]
+            m = re.match(r"void cf::(conv_igemm_kernel)<(\d+), (\d+), (\d+), (\d+), (\d+), \d+>", n)
+            if m:
+                n = "%s<%s,%s,%s,%s,%s>" % m.groups()
+            else:
+                n = re.sub(r"^void ", "", n).split("(")[0].replace("cf::", "")
+                n = re.sub(r"<.*>", "", n) if n.startswith("conv_smalln") else n
+            acc[n][0] += float(r["Counter_Value"])
+            acc[n][1] += 1
+    return acc
+
+
+def main():
+    fd, wd, out = sys.argv[1:4]
+    fe, wr = per_kernel(fd, "FETCH_SIZE"), per_kernel(wd, "WRITE_SIZE")
+    res = {}
+    for k in sorted(set(fe) | set(wr)):
+        f = fe.get(k, [0.0, 1])
+        w = wr.get(k, [0.0, 1])
+        res[k] = {"fetch_bytes_per_launch": round(2.0 * 1024.0 * f[0] / max(f[1], 1)),
+                  "write_bytes_per_launch": round(1024.0 * w[0] / max(w[1], 1)),
+                  "launches_sampled": int(max(f[1], w[1]))}
+        res[k]["bytes_per_launch"] = res[k]["fetch_bytes_per_launch"] + res[k]["write_bytes_per_launch"]
+    json.dump(res, open(out, "w"), indent=1)
+    for k, v in sorted(res.items(), key=lambda kv: -kv[1]["bytes_per_launch"] * kv[1]["launches_sampled"])[:12]:
+        print("%-44s %8.1f MB/launch (fetch %7.1f write %7.1f) x %d" % (k, v["bytes_per_launch"] / 1e6, v["fetch_bytes_per_launch"] / 1e6,
+                                                                          v["write_bytes_per_launch"] / 1e6, v["launches_sampled"]))
+
+
+if __name__ == "__main__":
+    main()
