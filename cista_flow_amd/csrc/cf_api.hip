@@ -1293,6 +1293,14 @@ extern "C" int cf_op_corr_lookup(const float* fmap1, const float* fmap2, const f
     return CF_OK;
 }
 
+// f-1: events -> normalised voxel grids (the step right before the hot path; utils/event_process.py)
+extern "C" int cf_events_to_voxel(const double* events, const int64_t* offsets, int B, int bins, int H, int W, float* voxel,
+                                  double* stats_scratch, int normalize, void* stream) {
+    static_assert(sizeof(long) == sizeof(int64_t), "LP64");
+    return launch_events_to_voxel(events, reinterpret_cast<const long*>(offsets), B, bins, H, W, voxel, stats_scratch,
+                                  normalize, static_cast<hipStream_t>(stream)) == hipSuccess ? CF_OK : CF_ERR_HIP;
+}
+
 extern "C" int cf_op_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, void* stream) {
     return launch_nchw_to_nhwc(src, dst, C, B, C, H * W, static_cast<hipStream_t>(stream)) == hipSuccess ? CF_OK : CF_ERR_HIP;
 }

@@ -641,6 +641,87 @@ hipError_t launch_idn_deblur(const float* bins, const float* flow, float* out, i
 }
 
 // ---------------------------------------------------------------------------
+// f-1: events -> voxel grid (utils/event_process.py:15-72) and 'std' normalisation (:193-216)
+// ---------------------------------------------------------------------------
+__global__ void events_scatter_kernel(const double* __restrict__ ev, const long* __restrict__ offsets, int B, int bins,
+                                      int H, int W, float* __restrict__ voxel) {
+    const int b = blockIdx.y;
+    const long e0 = offsets[b], e1 = offsets[b + 1];
+    const long n = e1 - e0;
+    if (n <= 0) return;
+    const double first = ev[e0 * 4], last = ev[(e1 - 1) * 4];
+    double deltaT = last - first;
+    if (deltaT == 0) deltaT = 1.0;
+    float* vox = voxel + (long)b * bins * H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const double* r = ev + (e0 + i) * 4;
+        const double ts = (double)(bins - 1) * (r[0] - first) / deltaT;
+        const unsigned long xs = (unsigned long)r[1], ys = (unsigned long)r[2];
+        double pol = r[3];
+        if (pol == 0) pol = -1;                       // polarity is +1 / -1
+        const unsigned long ti = (unsigned long)ts;
+        const double dt = ts - (double)ti;
+        if (xs >= (unsigned long)W || ys >= (unsigned long)H) continue;   // numpy would index out of range
+        const long base = (long)xs + (long)ys * W;
+        if (ti < (unsigned long)bins) atomicAdd(vox + base + (long)ti * W * H, (float)(pol * (1.0 - dt)));
+        if (ti + 1 < (unsigned long)bins) atomicAdd(vox + base + (long)(ti + 1) * W * H, (float)(pol * dt));
+    }
+}
+
+// stats[b] = {count of non-zeros, sum, sum of squares} (fp64)
+__global__ void voxel_stats_kernel(const float* __restrict__ voxel, long per_seq, double* __restrict__ stats) {
+    __shared__ double sh[3][256];
+    const int b = blockIdx.y;
+    const float* v = voxel + (long)b * per_seq;
+    double c = 0, s = 0, ss = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per_seq; i += (long)gridDim.x * blockDim.x) {
+        const double x = (double)v[i];
+        if (x != 0) c += 1.0;
+        s += x;
+        ss += x * x;
+    }
+    sh[0][threadIdx.x] = c; sh[1][threadIdx.x] = s; sh[2][threadIdx.x] = ss;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o)
+            for (int k = 0; k < 3; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 3; ++k) atomicAdd(stats + b * 3 + k, sh[k][0]);
+}
+
+__global__ void voxel_normalize_kernel(float* __restrict__ voxel, long per_seq, const double* __restrict__ stats) {
+    const int b = blockIdx.y;
+    const double cnt = stats[b * 3 + 0];
+    if (cnt <= 0) return;
+    const double mean = stats[b * 3 + 1] / cnt;
+    const double sd = sqrt(stats[b * 3 + 2] / cnt - mean * mean);
+    float* v = voxel + (long)b * per_seq;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per_seq; i += (long)gridDim.x * blockDim.x) {
+        const float x = v[i];
+        if (x != 0.f) v[i] = (float)(((double)x - mean) / (sd + 1e-8));
+    }
+}
+
+hipError_t launch_events_to_voxel(const double* events, const long* offsets, int B, int bins, int H, int W, float* voxel,
+                                  double* stats, int normalize, hipStream_t s) {
+    if (!events || !offsets || !voxel || B <= 0 || bins <= 0 || H <= 0 || W <= 0 || (normalize && !stats))
+        return hipErrorInvalidValue;
+    const long per_seq = (long)bins * H * W;
+    hipError_t e = hipMemsetAsync(voxel, 0, sizeof(float) * per_seq * B, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(events_scatter_kernel, dim3(64, B), dim3(256), 0, s, events, offsets, B, bins, H, W, voxel);
+    if (normalize) {
+        e = hipMemsetAsync(stats, 0, sizeof(double) * 3 * B, s);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(voxel_stats_kernel, dim3(64, B), dim3(256), 0, s, voxel, per_seq, stats);
+        hipLaunchKernelGGL(voxel_normalize_kernel, dim3(64, B), dim3(256), 0, s, voxel, per_seq, stats);
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // boundary shuffles (recurrent states arrive / leave as whatever the caller holds)
 // ---------------------------------------------------------------------------
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int dst_ld, int B, int C,

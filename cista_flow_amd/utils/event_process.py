@@ -1,0 +1,34 @@
+"""events -> voxel grid on the GPU (reference: utils/event_process.py:15-72 events_to_voxel_grid and :193-216
+event_preprocess('std')): the step right before the hot path.  Raw events (16-32 B each) are
+uploaded instead of dense voxel grids and the temporal-bilinear scatter + non-zero normalisation run as HIP
+kernels (float atomics: sums may differ from numpy's sequential np.add.at in the last bit)."""
+import torch
+
+from .. import lib as _lib
+
+
+def events_to_voxel_grid_batch(event_list, num_bins, width, height, normalize=True):
+    """event_list: B tensors [N_b, 4] float64 on the GPU, rows (timestamp, x, y, polarity) in time order.
+    Returns [B, num_bins, height, width] float32."""
+    if len(event_list) == 0:
+        raise ValueError("empty batch")
+    for e in event_list:
+        if not (isinstance(e, torch.Tensor) and e.is_cuda and e.dtype == torch.float64 and e.dim() == 2 and e.shape[1] == 4):
+            raise TypeError("events must be CUDA float64 tensors of shape [N, 4]")
+    dev = event_list[0].device
+    B = len(event_list)
+    ev = torch.cat([e.contiguous() for e in event_list], 0) if B > 1 else event_list[0].contiguous()
+    if ev.shape[0] == 0:
+        ev = torch.zeros((1, 4), dtype=torch.float64, device=dev)
+    off = [0]
+    for e in event_list:
+        off.append(off[-1] + int(e.shape[0]))
+    offsets = torch.tensor(off, dtype=torch.int64, device=dev)
+    voxel = torch.empty((B, num_bins, height, width), dtype=torch.float32, device=dev)
+    stats = torch.empty((B, 3), dtype=torch.float64, device=dev)
+    L = _lib.load()
+    rc = L.cf_events_to_voxel(_lib.ptr(ev), _lib.ptr(offsets), B, num_bins, height, width, _lib.ptr(voxel), _lib.ptr(stats),
+                              1 if normalize else 0, _lib.current_stream_ptr())
+    if rc != 0:
+        raise RuntimeError("cf_events_to_voxel failed (%d)" % rc)
+    return voxel

@@ -97,6 +97,12 @@ int cf_step(cf_handle* h, const float* in0, const float* in1, const float* rec_i
             const float* cc_prev, float* I_out, float* flow_final, float* flow_low, float* flow_preds,
             float* z_warped_out, float* c_out, float* z_out, float* h_out, float* cc_out, void* stream);
 
+/* f-1 (next row): events_to_voxel_grid + event_preprocess('std') (utils/event_process.py:15-72,193-216).
+ * events: device [total][4] fp64 rows (timestamp, x, y, polarity), the B sequences' events concatenated in time
+ * order; offsets: device int64 [B+1]; voxel: [B][bins][H][W] fp32; stats_scratch: 3*B doubles. */
+int cf_events_to_voxel(const double* events, const int64_t* offsets, int B, int bins, int H, int W, float* voxel,
+                       double* stats_scratch, int normalize, void* stream);
+
 /* measurement: when enabled, every convolution launch of the fused paths is bracketed by HIP events on
  * the launch stream.  cf_profile_read synchronises them and returns, for conv tile kind t = 1..6
  * (index 0 = all), the summed launch duration in ms, the summed algorithmic flops (2*M*N*K with the

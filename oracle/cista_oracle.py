@@ -564,3 +564,40 @@ def idnet_step(sd, batch_data, states, flow_init=None, warp_mode="forward", dept
             states[1] = warp(states[1], dflow, warp_mode)
     I_rec, new_states = cista_forward(sd, batch_data["event_voxel"], warped_I, states, depth=depth)
     return I_rec, bf, new_states
+
+
+# ----------------------------------------------------------------------------------------------
+# f-1: events -> voxel grid   /root/reference/utils/event_process.py:15-72, 193-216
+# ----------------------------------------------------------------------------------------------
+
+
+def events_to_voxel(events, num_bins, width, height, normalize=True):
+    """events: numpy [N,4] float64 (t, x, y, polarity).  Temporal-bilinear accumulation then, if `normalize`,
+    the 'std' pre-processing: non-zero voxels to mean 0 / std 1, zeros stay zero."""
+    import numpy as np
+    vox = np.zeros(num_bins * height * width, np.float32)
+    if len(events):
+        t = events[:, 0]
+        dT = t[-1] - t[0]
+        if dT == 0:
+            dT = 1.0
+        ts = (num_bins - 1) * (t - t[0]) / dT
+        xs = events[:, 1].astype(np.int64)
+        ys = events[:, 2].astype(np.int64)
+        pol = np.where(events[:, 3] == 0, -1.0, events[:, 3])
+        ti = ts.astype(np.int64)
+        dt = ts - ti
+        for k in range(len(events)):          # sequential like np.add.at
+            if ti[k] < num_bins:
+                vox[xs[k] + ys[k] * width + ti[k] * width * height] += pol[k] * (1.0 - dt[k])
+            if ti[k] + 1 < num_bins:
+                vox[xs[k] + ys[k] * width + (ti[k] + 1) * width * height] += pol[k] * dt[k]
+    vox = vox.reshape(num_bins, height, width)
+    if normalize:
+        nz = vox != 0
+        n = nz.sum()
+        if n > 0:
+            mean = vox.sum() / n
+            sd = np.sqrt((vox ** 2).sum() / n - mean ** 2)
+            vox = (nz.astype(np.float32) * (vox - mean) / (sd + 1e-8)).astype(np.float32)
+    return vox

@@ -113,6 +113,16 @@ def test_idnet_golden(name):
         prev = I.clone()
 
 
+def test_events_to_voxel_golden():
+    g = gu.load("events.npz")
+    for i in range(4):
+        H, W = [int(v) for v in g["dims_%d" % i]]
+        raw = orc.events_to_voxel(g["ev_%d" % i].copy(), 5, W, H, normalize=False)
+        nrm = orc.events_to_voxel(g["ev_%d" % i].copy(), 5, W, H, normalize=True)
+        assert gu.rel_err(raw, g["raw_%d" % i]) < 1e-6 or (abs(g["raw_%d" % i]).max() == 0 and abs(raw).max() == 0)
+        assert gu.rel_err(nrm, g["norm_%d" % i]) < 1e-5 or (abs(g["norm_%d" % i]).max() == 0 and abs(nrm).max() == 0)
+
+
 def test_state_dict_layout_matches_reference():
     """The shell modules must expose the reference's state_dict keys, shapes and order (262 entries)."""
     import argparse

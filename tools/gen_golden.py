@@ -144,6 +144,24 @@ def run_idnet(ref_model, H, W, B, frames, seed, name):
     print(name)
 
 
+def run_events(name):
+    """utils/event_process.py: events_to_voxel_grid + event_preprocess('std') of the reference itself."""
+    import utils.event_process as ep
+    rng = np.random.default_rng(7)
+    out = {}
+    for i, (N, H, W) in enumerate([(3000, 36, 52), (15000, 180, 240), (0, 20, 20), (1, 16, 16)]):
+        t = np.sort(rng.uniform(0.0, 0.03, N))
+        ev = np.stack([t, rng.integers(0, W, N).astype(np.float64), rng.integers(0, H, N).astype(np.float64),
+                       rng.integers(0, 2, N).astype(np.float64)], 1) if N else np.zeros((0, 4))
+        vox = ep.events_to_voxel_grid(ev.copy(), 5, W, H)
+        out["ev_%d" % i] = ev
+        out["raw_%d" % i] = vox.copy()
+        out["norm_%d" % i] = np.asarray(ep.event_preprocess(vox.copy(), "std"), dtype=np.float32)
+        out["dims_%d" % i] = np.array([H, W])
+    np.savez_compressed(os.path.join(GOLD, name), **out)
+    print(name)
+
+
 def run_cista(ref_model, H, W, B, frames, seed, name):
     from weights_util import fill_module, synth_events
     torch.manual_seed(0)
@@ -201,9 +219,9 @@ def main():
     with open(os.path.join(GOLD, "idnet_state_dict_layout.json"), "w") as f:
         json.dump([[k, list(v.shape)] for k, v in d.state_dict().items()], f)
     if "--only-new" in sys.argv:
-        run_idnet(ref_model, 68, 92, 2, 3, 41, "idnet_68x92.npz")
-        run_idnet(ref_model, 260, 346, 1, 2, 42, "idnet_260x346.npz")
+        run_events("events.npz")
         return
+    run_events("events.npz")
     run_idnet(ref_model, 68, 92, 2, 3, 41, "idnet_68x92.npz")
     run_idnet(ref_model, 260, 346, 1, 2, 42, "idnet_260x346.npz")
     run_eraft(ref_model, 100, 124, 2, 3, 31, "eraft_100x124.npz")
