@@ -39,6 +39,7 @@ struct RawWeight {
 
 struct PackedConv {
     float* w = nullptr;
+    void* w16 = nullptr;     // f16 hi/lo split copy (precision != 0)
     float* bias = nullptr;
     int cout = 0, cin = 0, cin_pad = 0, KH = 0, KW = 0, Ktot = 0, rows = 0;
     bool gather = false;
@@ -136,7 +137,9 @@ struct cf_handle {
 
 // every convolution of the graphs goes through here (optional HIP-event bracketing)
 #define TAG(h, t) ((h)->tag = (t))
-static hipError_t run_conv(cf_handle* h, const ConvParams& p, int batch, hipStream_t st, int tile = 0) {
+static hipError_t run_conv(cf_handle* h, const ConvParams& p_in, int batch, hipStream_t st, int tile = 0) {
+    ConvParams p = p_in;
+    p.prec = h ? h->cfg.precision : 0;
     if (!h || !h->prof) return launch_conv(p, batch, st, tile);
     cf_handle::ProfRec r;
     r.a = h->prof_event();
@@ -270,7 +273,7 @@ ConvParams nhwc_conv(const PackedConv& pc, std::initializer_list<Seg> segs, int 
     p.Hin = Hin; p.Win = Win; p.Hsrc = Hin; p.Wsrc = Win; p.Ho = Ho; p.Wo = Wo;
     p.KH = pc.KH; p.KW = pc.KW; p.stride = stride; p.padT = padT; p.padL = padL; p.pad_mode = pad_mode;
     p.a_mode = A_NHWC;
-    p.w = pc.w; p.w_bs = 0; p.w_rows = pc.rows; p.Ktot = pc.Ktot; p.cin_pad = pc.cin_pad; p.bias = pc.bias;
+    p.w = pc.w; p.w16 = pc.w16; p.w_bs = 0; p.w_rows = pc.rows; p.Ktot = pc.Ktot; p.cin_pad = pc.cin_pad; p.bias = pc.bias;
     p.out = out; p.out_ld = out_ld; p.out_bs = out_bs; p.cout = pc.cout; p.epi = epi;
     p.k_real = pc.cin * pc.KH * pc.KW;
     p.tag = pc.name.c_str();
@@ -287,7 +290,7 @@ ConvParams gather_conv(const PackedConv& pc, const float* in, int Cin, int Hsrc,
     p.KH = pc.KH; p.KW = pc.KW; p.stride = stride; p.padT = padT; p.padL = padL; p.pad_mode = pad_mode;
     p.a_mode = A_GATHER;
     p.g_cin = Cin; p.g_offy = offy; p.g_offx = offx; p.g_scale = scale; p.g_shift = shift; p.g_subgrid = subgrid;
-    p.w = pc.w; p.w_rows = pc.rows; p.Ktot = pc.Ktot; p.cin_pad = 0; p.bias = pc.bias;
+    p.w = pc.w; p.w16 = pc.w16; p.w_rows = pc.rows; p.Ktot = pc.Ktot; p.cin_pad = 0; p.bias = pc.bias;
     p.out = out; p.out_ld = out_ld; p.out_bs = out_bs; p.cout = pc.cout; p.epi = epi;
     p.k_real = pc.cin * pc.KH * pc.KW;
     p.tag = pc.name.c_str();
@@ -529,6 +532,16 @@ extern "C" int cf_finalize_weights(cf_handle* h, void* stream) {
             h->has_flow = true;
         }
     }
+    if (h->cfg.precision != 0) {
+        // f16 modes: every packed matrix gets a hi/lo split copy in the LDS chunk format (same byte size)
+        for (auto& kv : h->conv) {
+            PackedConv& pc = kv.second;
+            if (!pc.w) continue;
+            CF_HIP(h, hipMalloc(&pc.w16, (size_t)pc.rows * pc.Ktot * sizeof(float)));
+            h->owned.push_back(pc.w16);
+            CF_HIP(h, launch_split_weight_f16(pc.w, pc.w16, pc.rows, pc.Ktot, st));
+        }
+    }
     // the announced pointers may die after this call: drain the packing kernels
     CF_HIP(h, hipStreamSynchronize(st));
     h->raw.clear();
@@ -555,6 +568,7 @@ extern "C" int cf_create(cf_handle** out, const cf_config* cfg) {
     if (cfg->base_channels < 32 || (cfg->base_channels % 32) != 0) return bad("cf_create: base_channels must be a multiple of 32");
     if (cfg->depth < 1) return bad("cf_create: bad depth");
     if (cfg->mode < CF_MODE_CISTA || cfg->mode > CF_MODE_IDNET) return bad("cf_create: unknown mode");
+    if (cfg->precision != 0 && cfg->precision != 1 && cfg->precision != 3) return bad("cf_create: precision must be 0 (fp32), 3 (f16x3) or 1 (f16)");
     if ((cfg->mode == CF_MODE_EIFLOW || cfg->mode == CF_MODE_ERAFT) && cfg->iters < 1) return bad("cf_create: bad iters");
     cf_handle* h = new cf_handle();
     h->cfg = *cfg;
@@ -1180,7 +1194,7 @@ struct TmpBuf {
 
 static int op_conv2d_impl(const float* in, int B, int Cin, int H, int W, const float* weight, const float* bias, int Cout,
                           int KH, int KW, int stride, int padT, int padL, int pad_mode, int a_mode, int epi, int tile,
-                          float* out, void* stream, int iters, float* ms_out) {
+                          float* out, void* stream, int iters, float* ms_out, int prec) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (!in || !weight || !out || B < 1 || Cin < 1 || Cout < 1 || stride < 1) return CF_ERR_ARG;
     const bool gather = a_mode == A_GATHER;
@@ -1214,6 +1228,13 @@ static int op_conv2d_impl(const float* in, int B, int Cin, int H, int W, const f
             p.Wsrc = W;
         }
     }
+    TmpBuf w16;
+    if (prec != 0) {
+        if (hipMalloc(&w16.p, (size_t)pc.rows * pc.Ktot * sizeof(float)) != hipSuccess) return CF_ERR_HIP;
+        if (launch_split_weight_f16(pc.w, w16.p, pc.rows, pc.Ktot, st) != hipSuccess) return CF_ERR_HIP;
+        p.w16 = w16.p;
+        p.prec = prec;
+    }
     hipError_t e = launch_conv(p, B, st, tile);
     if (e != hipSuccess) return e == hipErrorInvalidValue ? CF_ERR_ARG : CF_ERR_HIP;
     if (iters > 0 && ms_out) {   // timing loop for tools/conv_bench.py
@@ -1237,15 +1258,15 @@ extern "C" int cf_op_conv2d(const float* in, int B, int Cin, int H, int W, const
                             int KH, int KW, int stride, int padT, int padL, int pad_mode, int a_mode, int epi, int tile,
                             float* out, void* stream) {
     return op_conv2d_impl(in, B, Cin, H, W, weight, bias, Cout, KH, KW, stride, padT, padL, pad_mode, a_mode, epi, tile, out,
-                          stream, 0, nullptr);
+                          stream, 0, nullptr, 0);
 }
 
 // same op launched `iters` times between two HIP events; *ms_out = average launch duration (tuning tool)
 extern "C" int cf_op_conv2d_bench(const float* in, int B, int Cin, int H, int W, const float* weight, const float* bias,
                                   int Cout, int KH, int KW, int stride, int padT, int padL, int pad_mode, int a_mode,
-                                  int epi, int tile, float* out, void* stream, int iters, float* ms_out) {
+                                  int epi, int tile, float* out, void* stream, int iters, float* ms_out, int prec) {
     return op_conv2d_impl(in, B, Cin, H, W, weight, bias, Cout, KH, KW, stride, padT, padL, pad_mode, a_mode, epi, tile, out,
-                          stream, iters, ms_out);
+                          stream, iters, ms_out, prec);
 }
 
 extern "C" int cf_op_instance_norm_relu(const float* x, float* out, int B, int C, int H, int W, float eps, void* stream) {

@@ -62,6 +62,7 @@ struct ConvParams {
     float g_scale, g_shift;
     // ---- B operand (packed weights [w_rows][Ktot], K contiguous) ----
     const float* w;
+    const void* w16;    // f16 split copy of w (nullable; f16 modes fall back to splitting B while staging)
     long w_bs;          // batch stride (0 for ordinary weights; N*D for the correlation GEMM)
     int  w_rows;        // valid rows in the packed matrix
     int  Ktot;          // taps * cin_pad (A_NHWC/A_UPS2X) or round16(taps*Cin) (A_GATHER)
@@ -82,12 +83,16 @@ struct ConvParams {
     const float* addend; int addend_ld; long addend_bs;   // v += addend[b][m][n] before the epilogue op
     int  k_real;        // un-padded K (taps * Cin): algorithmic-flop bookkeeping only
     const char* tag;    // layer name for the profiler (host side only)
+    int  prec;          // 0 fp32 MFMA, 3 f16x3 split MFMA, 1 plain f16 MFMA (w must point at the matching copy)
+    int  b_f32;         // f16 modes: B operand is fp32 activations (correlation GEMM), split while staging
     int  sched;         // workgroup->tile map: -1 default (env CF_SCHED, else 1), 0 m-fastest, 1 XCD-aware
 };
 
 // tile: 0 auto, else explicit (see conv_igemm.hip); tile_used (nullable) returns the choice
 hipError_t launch_conv(const ConvParams& p, int batch, hipStream_t s, int tile = 0, int* tile_used = nullptr);
 const char* conv_tile_name(int tile);
+// f16 split copy of a packed weight matrix (same byte size, LDS chunk format [16 hi | 16 lo])
+hipError_t launch_split_weight_f16(const float* src, void* dst, long rows, int Ktot, hipStream_t s);
 
 // ---------------------------------------------------------------------------
 // Weight packing (device side, runs once per load_state_dict)

@@ -26,6 +26,8 @@ namespace cf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 static constexpr int KC = 16;      // K chunk (floats)
 static constexpr int LDS_S = 20;   // LDS row stride (floats)
@@ -37,6 +39,18 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
     i = i < 0 ? -i : i;
     i = i >= n ? 2 * (n - 1) - i : i;
     return i;
+}
+
+// f16 split of an fp32 value: hi = f16(x) (saturated to the f16 range), lo = f16(x - hi).  hi + lo carries 22
+// mantissa bits; products of f16 values are exact in the fp32 accumulator of v_mfma_f32_32x32x16_f16.
+__device__ __forceinline__ void split_f16(const f32x4& v, f16x4& hi, f16x4& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x = fminf(fmaxf(v[e], -65504.f), 65504.f);
+        const _Float16 h = (_Float16)x;
+        hi[e] = h;
+        lo[e] = (_Float16)(x - (float)h);
+    }
 }
 
 __device__ __forceinline__ const float* sel3(const float* const (&a)[3], int s) {
@@ -195,7 +209,13 @@ __device__ __forceinline__ void epilogue4(const ConvParams& p, int b, int m, int
 // 16*WK k-columns and wave (.., wk) consumes columns [16*wk, 16*wk+16).  The partial accumulators are summed
 // through LDS before the epilogue.  This keeps 4 waves busy on 32x32 / 32x64 output tiles, which is what the
 // 1/8-resolution layers (M = 768 pixels per image) need to fill 256 CUs.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int WK, int AMODE>
+// PREC: 0 = v_mfma_f32_32x32x2_f32 on fp32 operands (exact fp32 products);
+//       3 = "f16x3": operands split hi+lo into f16 while staging, 3 x v_mfma_f32_32x32x16_f16 (hi*hi + hi*lo +
+//           lo*hi, fp32 accumulate) -- fp32-grade products at 16/3 of the fp32-MFMA rate;
+//       1 = plain f16 operands, one MFMA (the reduced-precision mode BASELINE configs[4] names).
+// In the f16 modes an LDS row holds, per 16-column chunk, [16 x hi | 16 x lo] (64 bytes): the same bytes as
+// 16 fp32, so tile geometry, strides and the pre-split weight copies (same format in HBM) are shared.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int WK, int AMODE, int PREC>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     static_assert(WAVES_M * WAVES_N * WK == 4, "4 waves per workgroup");
     static_assert(BM % 32 == 0 && BN % 32 == 0, "tiles are multiples of the 32x32 MFMA");
@@ -448,12 +468,38 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     auto store_chunk = [&](int buf) {
         float* sA = smem + buf * STAGE;
         float* sB = sA + BM * LS;
+        if (PREC == 0) {
 #pragma unroll
-        for (int j = 0; j < A_IT; ++j)
-            if (a_live[j]) *reinterpret_cast<f32x4*>(sA + a_row[j] * LS + a_q[j] * 4) = a_reg[j];
+            for (int j = 0; j < A_IT; ++j)
+                if (a_live[j]) *reinterpret_cast<f32x4*>(sA + a_row[j] * LS + a_q[j] * 4) = a_reg[j];
 #pragma unroll
-        for (int it = 0; it < B_IT; ++it)
-            if (b_live[it]) *reinterpret_cast<f32x4*>(sB + b_row[it] * LS + b_q[it] * 4) = b_reg[it];
+            for (int it = 0; it < B_IT; ++it)
+                if (b_live[it]) *reinterpret_cast<f32x4*>(sB + b_row[it] * LS + b_q[it] * 4) = b_reg[it];
+        } else {
+            // quad q of a row = k 4q..4q+3 -> chunk q/4: hi at chunk*64 + (q%4)*8 bytes, lo 32 bytes further
+#pragma unroll
+            for (int j = 0; j < A_IT; ++j) {
+                if (!a_live[j]) continue;
+                f16x4 hi, lo;
+                split_f16(a_reg[j], hi, lo);
+                char* dst = reinterpret_cast<char*>(sA + a_row[j] * LS) + (a_q[j] >> 2) * 64 + (a_q[j] & 3) * 8;
+                *reinterpret_cast<f16x4*>(dst) = hi;
+                if (PREC == 3) *reinterpret_cast<f16x4*>(dst + 32) = lo;
+            }
+#pragma unroll
+            for (int it = 0; it < B_IT; ++it) {
+                if (!b_live[it]) continue;
+                if (p.b_f32) {   // B operand is an activation (all-pairs correlation): split it here as well
+                    f16x4 hi, lo;
+                    split_f16(b_reg[it], hi, lo);
+                    char* dst = reinterpret_cast<char*>(sB + b_row[it] * LS) + (b_q[it] >> 2) * 64 + (b_q[it] & 3) * 8;
+                    *reinterpret_cast<f16x4*>(dst) = hi;
+                    if (PREC == 3) *reinterpret_cast<f16x4*>(dst + 32) = lo;
+                } else {         // weights were split at pack time: HBM rows already have the LDS format
+                    *reinterpret_cast<f32x4*>(sB + b_row[it] * LS + b_q[it] * 4) = b_reg[it];
+                }
+            }
+        }
     };
 
     load_chunk();
@@ -467,6 +513,32 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         if (ck + 1 < nck) load_chunk();
         const float* sA = smem + buf * STAGE + wk * KC;
         const float* sB = smem + buf * STAGE + BM * LS + wk * KC;
+        if (PREC != 0) {
+            // one v_mfma_f32_32x32x16_f16 spans the whole 16-column chunk: lane (r, h) holds k = 8h..8h+7
+            f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const char* r = reinterpret_cast<const char*>(sA + ((wm * TM + i) * 32 + lr) * LS) + lh * 16;
+                ah[i] = *reinterpret_cast<const f16x8*>(r);
+                if (PREC == 3) al[i] = *reinterpret_cast<const f16x8*>(r + 32);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const char* r = reinterpret_cast<const char*>(sB + ((wn * TN + j) * 32 + lr) * LS) + lh * 16;
+                bh[j] = *reinterpret_cast<const f16x8*>(r);
+                if (PREC == 3) bl[j] = *reinterpret_cast<const f16x8*>(r + 32);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (PREC == 3) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        } else
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             f32x4 af[TM], bf[TN];
@@ -543,19 +615,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, int WK>
-static hipError_t launch_t(const ConvParams& p, int batch, hipStream_t s) {
+template <int BM, int BN, int WM, int WN, int WK, int PREC>
+static hipError_t launch_tp(const ConvParams& p, int batch, hipStream_t s) {
     const int M = p.Ho * p.Wo;
     dim3 grid(((M + BM - 1) / BM) * ((p.cout + BN - 1) / BN) * batch);
     if (p.a_mode == A_NHWC) {
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, WK, A_NHWC>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, WK, A_NHWC, PREC>), grid, dim3(256), 0, s, p);
     } else if constexpr (WK == 1) {
-        if (p.a_mode == A_UPS2X) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1, A_UPS2X>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1, A_GATHER>), grid, dim3(256), 0, s, p);
+        if (p.a_mode == A_UPS2X) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1, A_UPS2X, PREC>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1, A_GATHER, PREC>), grid, dim3(256), 0, s, p);
     } else {
         return hipErrorInvalidValue;
     }
     return hipGetLastError();
+}
+
+template <int BM, int BN, int WM, int WN, int WK>
+static hipError_t launch_t(const ConvParams& p, int batch, hipStream_t s) {
+    if (p.prec == 3) return launch_tp<BM, BN, WM, WN, WK, 3>(p, batch, s);
+    if (p.prec == 1) return launch_tp<BM, BN, WM, WN, WK, 1>(p, batch, s);
+    return launch_tp<BM, BN, WM, WN, WK, 0>(p, batch, s);
 }
 
 // split-K tiles need every channel segment to be a whole number of stages
@@ -737,6 +816,15 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
         }
     }
     if (tile_used) *tile_used = tile;
+    if (p.prec != 0 && p.prec != 1 && p.prec != 3) return hipErrorInvalidValue;
+    if (p.prec != 0) {          // f16 modes: pre-split weights when there are some, else split B while staging
+        if (p.w16 && p.w_bs == 0) {
+            p.w = static_cast<const float*>(p.w16);
+            p.b_f32 = 0;
+        } else {
+            p.b_f32 = 1;
+        }
+    }
     switch (tile) {
         case 1: return launch_t<128, 128, 2, 2, 1>(p, batch, s);
         case 2: return launch_t<128, 64, 2, 2, 1>(p, batch, s);
@@ -799,6 +887,27 @@ hipError_t launch_pack_weight(const float* src, float* dst, int Cout, int Cin, i
     hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)blocks), dim3(threads), 0, s, src, dst, Cout, Cin, KH, KW,
                        cin_pad, Ktot, row0, gather, c_begin, c_count, dst_coff, accum, bn_w, bn_b, bn_mean, bn_var, bn_eps,
                        bias_src, bias_dst);
+    return hipGetLastError();
+}
+
+// fp32 packed matrix [rows][Ktot] -> f16 split copy with the LDS chunk format: per 16-column chunk 16 x hi then
+// 16 x lo (64 bytes, the footprint of the 16 fp32 it replaces)
+__global__ void split_weight_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = fminf(fmaxf(src[i], -65504.f), 65504.f);
+    const _Float16 h = (_Float16)x;
+    const long chunk = i >> 4;
+    const int j = (int)(i & 15);
+    dst[chunk * 32 + j] = h;
+    dst[chunk * 32 + 16 + j] = (_Float16)(x - (float)h);
+}
+
+hipError_t launch_split_weight_f16(const float* src, void* dst, long rows, int Ktot, hipStream_t s) {
+    const long n = rows * Ktot;
+    if (!src || !dst || n <= 0 || (Ktot % 16) != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(split_weight_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src,
+                       static_cast<_Float16*>(dst), n);
     return hipGetLastError();
 }
 

@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libcistaflow.so")
 
 CF_MODE_CISTA, CF_MODE_EIFLOW, CF_MODE_ERAFT, CF_MODE_IDNET = 0, 1, 2, 3
 CF_WARP_FORWARD, CF_WARP_BACKWARD = 0, 1
+PRECISIONS = {"f32": 0, "f16x3": 3, "f16": 1}
 
 # every symbol include/cistaflow.h declares (tests check the .so exports exactly these)
 SYMBOLS = [
@@ -25,7 +26,7 @@ class cf_config(C.Structure):
     _fields_ = [
         ("mode", C.c_int), ("batch", C.c_int), ("height", C.c_int), ("width", C.c_int),
         ("num_bins", C.c_int), ("base_channels", C.c_int), ("depth", C.c_int), ("iters", C.c_int),
-        ("warp_mode", C.c_int), ("device", C.c_int),
+        ("warp_mode", C.c_int), ("device", C.c_int), ("precision", C.c_int),
     ]
 
 
@@ -68,7 +69,7 @@ def load():
     lib.cf_step.restype = i
     lib.cf_op_conv2d.argtypes = [fp, i, i, i, i, fp, fp, i, i, i, i, i, i, i, i, i, i, fp, vp]
     lib.cf_op_conv2d.restype = i
-    lib.cf_op_conv2d_bench.argtypes = [fp, i, i, i, i, fp, fp, i, i, i, i, i, i, i, i, i, i, fp, vp, i, C.POINTER(C.c_float)]
+    lib.cf_op_conv2d_bench.argtypes = [fp, i, i, i, i, fp, fp, i, i, i, i, i, i, i, i, i, i, fp, vp, i, C.POINTER(C.c_float), i]
     lib.cf_op_conv2d_bench.restype = i
     lib.cf_op_instance_norm_relu.argtypes = [fp, fp, i, i, i, i, C.c_float, vp]
     lib.cf_op_instance_norm_relu.restype = i
@@ -120,9 +121,10 @@ class Handle:
     """Owns one cf_handle (workspace arena + packed weights) for a fixed (mode, B, H, W)."""
 
     def __init__(self, mode, batch, height, width, num_bins=5, base_channels=64, depth=5, iters=6,
-                 warp_mode=CF_WARP_FORWARD, device=0):
+                 warp_mode=CF_WARP_FORWARD, device=0, precision=0):
         self.lib = load()
-        self.cfg = cf_config(mode, batch, height, width, num_bins, base_channels, depth, iters, warp_mode, device)
+        self.cfg = cf_config(mode, batch, height, width, num_bins, base_channels, depth, iters, warp_mode, device,
+                             precision)
         h = C.c_void_p()
         rc = self.lib.cf_create(C.byref(h), C.byref(self.cfg))
         if rc != 0:

@@ -7,6 +7,11 @@ from . import lib as _lib
 
 class HipBackend(object):
     def __init__(self, module, mode, image_dim, num_bins=5, base_channels=64, depth=5, iters=6, warp_mode='forward'):
+        import os
+        # arithmetic of the conv products: module.precision ("f32" default | "f16x3" | "f16"), env CF_PRECISION overrides
+        self.precision = os.environ.get("CF_PRECISION") or getattr(module, "precision", "f32")
+        if self.precision not in _lib.PRECISIONS:
+            raise ValueError("precision must be one of %s" % sorted(_lib.PRECISIONS))
         self.module = module
         self.mode = mode
         self.image_dim = (int(image_dim[0]), int(image_dim[1]))
@@ -28,7 +33,8 @@ class HipBackend(object):
         key = (int(batch), idx)
         ent = self.handles.get(key)
         if ent is None:
-            h = _lib.Handle(self.mode, int(batch), self.image_dim[0], self.image_dim[1], device=idx, **self.kw)
+            h = _lib.Handle(self.mode, int(batch), self.image_dim[0], self.image_dim[1], device=idx,
+                            precision=_lib.PRECISIONS[self.precision], **self.kw)
             ent = [h, None]
             self.handles[key] = ent
         sig = self._signature()

@@ -52,6 +52,11 @@ typedef struct cf_config {
     int iters;          /* flow-net refinement iterations: 6 eiflow (DCEIFlow.py:143), 12 eraft */
     int warp_mode;      /* CF_WARP_* (configs.py:94) */
     int device;         /* HIP device ordinal */
+    int precision;      /* arithmetic of the convolution products (fp32 tensors and accumulation in every mode):
+                           0 = exact fp32 (v_mfma_f32_32x32x2_f32)                              -- the default
+                           3 = "f16x3": operands split hi+lo into f16, hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16
+                               (22-bit products, ~2e-5 end-to-end vs the reference)
+                           1 = plain f16 products (reduced precision; BASELINE configs[4] "fp16 with MFMA") */
 } cf_config;
 
 /* lifetime ---------------------------------------------------------------------------------- */
@@ -122,7 +127,7 @@ int cf_op_conv2d(const float* in, int B, int Cin, int H, int W, const float* wei
 /* tuning tool: the same conv launched `iters` times between two HIP events; *ms_out = avg launch ms */
 int cf_op_conv2d_bench(const float* in, int B, int Cin, int H, int W, const float* weight, const float* bias, int Cout,
                        int KH, int KW, int stride, int padT, int padL, int pad_mode, int a_mode, int epi, int tile,
-                       float* out, void* stream, int iters, float* ms_out);
+                       float* out, void* stream, int iters, float* ms_out, int precision);
 int cf_op_instance_norm_relu(const float* x_nhwc, float* out_nhwc, int B, int C, int H, int W, float eps,
                              void* stream);
 /* all-pairs correlation + pyramid + lookup (a9/a10): fmaps NHWC [B][h][w][D], coords NCHW [B][2][h][w];

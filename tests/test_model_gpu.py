@@ -261,3 +261,26 @@ def test_inputs_are_validated(gpu):
     with pytest.raises(TypeError):
         m({"event_voxel": torch.zeros(1, 5, 128, 128, device=gpu, dtype=torch.float64),
            "rec_img0": torch.zeros(1, 1, 128, 128, device=gpu)}, None, {})
+
+
+def test_eiflow_f16x3_precision_mode(gpu):
+    """Opt-in f16x3 arithmetic (3 x f16 MFMA per product, fp32 accumulate): still far inside the 1e-3 bar."""
+    g = gu.load("eiflow_100x124.npz")
+    H, W, B, frames, seed = [int(v) for v in g["meta"]]
+    from cista_flow_amd.e2v.e2v_model import DCEIFlowCistaNet
+    m = DCEIFlowCistaNet(args_for(H, W)).eval()
+    m.precision = "f16x3"
+    wu.fill_module(m, seed)
+    m = m.to(gpu)
+    states, prev = None, torch.zeros(B, 1, H, W, device=gpu)
+    worst = 0.0
+    with torch.no_grad():
+        for t in range(frames):
+            ev = torch.from_numpy(g["ev_%d" % t]).to(gpu)
+            I, bf, states = m({"event_voxel": ev, "rec_img0": prev}, states, {})
+            errs = [gu.rel_err(bf["flow_final"].cpu(), g["flow_%d" % t]), gu.rel_err(I.cpu(), g["I_%d" % t]),
+                    gu.rel_err(gu.sub(states[1].cpu()), g["z_%d" % t]), gu.rel_err(gu.sub(states[0].cpu()), g["c_%d" % t]),
+                    gu.rel_err(gu.sub(states[2][0].cpu()), g["h_%d" % t])]
+            worst = max(worst, max(errs))
+            prev = I.clone()
+    assert worst < 3e-4, worst

@@ -293,3 +293,27 @@ def test_events_to_voxel_gpu(gpu):
     assert out[1].abs().max() == 0
     one = events_to_voxel_grid_batch([evs[2]], 5, W, H).cpu()
     assert gu.rel_err(out[2], one[0]) < 1e-6
+
+
+@pytest.mark.parametrize("prec,tol", [(3, 2e-5), (1, 4e-3)])
+@pytest.mark.parametrize("case", [(192, 256, 3, 1, 1, 0), (128, 64, 3, 1, 1, 4), (384, 128, 3, 1, 1, 9), (64, 64, 3, 2, 1, 2),
+                                  (128, 128, 3, 1, 0, 8)])
+def test_conv_f16_split_modes(gpu, case, prec, tol):
+    """precision 3 (f16x3 split MFMA) must stay fp32-grade; precision 1 (plain f16 products) is the reduced mode."""
+    L, lib = _lib()
+    Cin, Cout, K, stride, pad_mode, tile = case
+    g = torch.Generator().manual_seed(Cin + Cout + tile)
+    B, H, W = 2, 20, 28
+    x = torch.randn(B, Cin, H, W, generator=g) * 3.0
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = ref_conv(x.double(), w.double(), b.double(), stride, 1, 1, pad_mode).float()
+    xin, wg, bg = nhwc(x).to(gpu), w.to(gpu), b.to(gpu)
+    out = torch.full((B, ref.shape[2], ref.shape[3], Cout), float("nan"), device=gpu)
+    ms = C.c_float(0)
+    rc = L.cf_op_conv2d_bench(lib.ptr(xin), B, Cin, H, W, lib.ptr(wg), lib.ptr(bg), Cout, K, K, stride, 1, 1, pad_mode, 0, 0,
+                              tile, lib.ptr(out), lib.current_stream_ptr(), 1, C.byref(ms), prec)
+    assert rc == 0
+    torch.cuda.synchronize()
+    err = ((nchw(out.cpu()) - ref).abs().max() / ref.abs().max()).item()
+    assert err < tol, err

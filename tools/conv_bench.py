@@ -31,6 +31,9 @@ SHAPES = [
 ]
 
 
+PREC = int(os.environ.get("PREC", "0"))
+
+
 def run(shape, tile, iters=20):
     name, B, Cin, H, W, Cout, KH, KW, stride, pT, pL, pm = shape
     x = torch.randn(B, H, W, Cin, device=dev)
@@ -41,7 +44,7 @@ def run(shape, tile, iters=20):
     out = torch.empty(B, Ho, Wo, Cout, device=dev)
     ms = C.c_float(0)
     rc = L.cf_op_conv2d_bench(lib.ptr(x), B, Cin, H, W, lib.ptr(w), lib.ptr(b), Cout, KH, KW, stride, pT, pL, pm, 0, 0,
-                              tile, lib.ptr(out), lib.current_stream_ptr(), iters, C.byref(ms))
+                              tile, lib.ptr(out), lib.current_stream_ptr(), iters, C.byref(ms), PREC)
     if rc != 0:
         return None
     flops = 2.0 * B * Ho * Wo * Cout * Cin * KH * KW
