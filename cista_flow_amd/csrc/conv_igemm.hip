@@ -328,6 +328,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 
     // ---- chunk iterator (wave-uniform): tap (ky,kx), channel segment, channel offset inside it ----
     int it_ky = 0, it_kx = 0, it_seg = 0, it_cs = 0, it_k = 0;
+    const int nseg = p.nseg, kw_n = p.KW;
     const float* seg_base = p.in[0] + (long)b * p.seg_bs[0];
     int seg_ld = p.seg_ld[0], seg_cn = p.seg_c[0];
 
@@ -337,20 +338,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     int u_p01[A_IT], u_p10[A_IT], u_p11[A_IT];
     float u_ly1[A_IT], u_lx1[A_IT];
 
-    auto tap_setup = [&]() {
+    const int g_hin = p.Hin, g_win = p.Win, g_padm = p.pad_mode;
+    auto tap_setup = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < A_IT; ++j) {
             int iy = a_oy[j] + it_ky;
             int ix = a_ox[j] + it_kx;
             bool ok = a_ok[j];
-            if (p.pad_mode == 1) {
-                iy = reflect_idx(iy, p.Hin);
-                ix = reflect_idx(ix, p.Win);
+            if (g_padm == 1) {
+                iy = reflect_idx(iy, g_hin);
+                ix = reflect_idx(ix, g_win);
             } else {
-                ok = ok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+                ok = ok && iy >= 0 && iy < g_hin && ix >= 0 && ix < g_win;
             }
             if (AMODE == A_NHWC) {
-                a_pix[j] = ok ? iy * p.Win + ix : -1;
+                a_pix[j] = ok ? iy * g_win + ix : -1;
             } else {   // A_UPS2X: bilinear x2 (align_corners=False) source taps of the (Hsrc,Wsrc) plane
                 float sy = ((float)iy + 0.5f) * 0.5f - 0.5f;
                 float sx = ((float)ix + 0.5f) * 0.5f - 0.5f;
@@ -371,14 +373,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     if (AMODE != A_GATHER) tap_setup();
 
     f32x4 a_reg[A_IT], b_reg[B_IT];
+    bool a_zero[A_IT];
+#pragma unroll
+    for (int j = 0; j < A_IT; ++j) a_zero[j] = false;
 
-    auto load_chunk = [&]() {
+    auto load_chunk = [&]() __attribute__((always_inline)) {
         // ---- B: packed weights, K contiguous ----
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (b_ok[it]) v = *reinterpret_cast<const f32x4*>(b_ptr[it] + it_k);
-            b_reg[it] = v;
+            // unconditional load (rows past the matrix were redirected to row 0) + select: a branch around the
+            // load would serialise the wave and drain vmcnt per element
+            b_reg[it] = *reinterpret_cast<const f32x4*>(b_ptr[it] + it_k);   // zeroed at store time if !b_ok
         }
         // ---- A ----
         if (AMODE == A_GATHER) {
@@ -404,13 +409,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                     const int sy = iy - p.g_offy;
                     const int sx = ix - p.g_offx;
                     ok = ok && sy >= 0 && sx >= 0;
-                    float x = 0.f;
-                    if (ok) {
-                        x = src[(c * p.Hsrc + sy) * p.Wsrc + sx];
-                        x = x * p.g_scale + p.g_shift;
-                        if (p.g_subgrid) x -= (c == 0) ? (float)sx : (float)sy;
-                    }
-                    v[e] = x;
+                    float x = src[ok ? (c * p.Hsrc + sy) * p.Wsrc + sx : 0];
+                    x = x * p.g_scale + p.g_shift;
+                    if (p.g_subgrid) x -= (c == 0) ? (float)sx : (float)sy;
+                    v[e] = ok ? x : 0.f;
                 }
                 a_reg[j] = v;
             }
@@ -418,18 +420,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             const float* src = seg_base + it_cs;
 #pragma unroll
             for (int j = 0; j < A_IT; ++j) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (a_pix[j] >= 0) v = *reinterpret_cast<const f32x4*>(src + (long)a_pix[j] * seg_ld + a_q[j] * 4);
-                a_reg[j] = v;
+                // padding taps read pixel 0; the zeroing happens at LDS-store time (a_zero) so that the loaded
+                // value is not touched -- and hence not waited for -- before this chunk's MFMAs
+                const int pix = a_pix[j] < 0 ? 0 : a_pix[j];
+                a_zero[j] = a_pix[j] < 0;
+                a_reg[j] = *reinterpret_cast<const f32x4*>(src + (long)pix * seg_ld + a_q[j] * 4);
             }
         } else {
             const float* src = seg_base + it_cs;
 #pragma unroll
             for (int j = 0; j < A_IT; ++j) {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (a_pix[j] >= 0) {
+                {
                     const int qo = a_q[j] * 4;
-                    const f32x4 v00 = *reinterpret_cast<const f32x4*>(src + (long)a_pix[j] * seg_ld + qo);
+                    const int p00 = a_pix[j] < 0 ? 0 : a_pix[j];
+                    const f32x4 v00 = *reinterpret_cast<const f32x4*>(src + (long)p00 * seg_ld + qo);
                     const f32x4 v01 = *reinterpret_cast<const f32x4*>(src + (long)u_p01[j] * seg_ld + qo);
                     const f32x4 v10 = *reinterpret_cast<const f32x4*>(src + (long)u_p10[j] * seg_ld + qo);
                     const f32x4 v11 = *reinterpret_cast<const f32x4*>(src + (long)u_p11[j] * seg_ld + qo);
@@ -438,6 +443,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         v[e] = ly0 * (lx0 * v00[e] + lx1 * v01[e]) + ly1 * (lx0 * v10[e] + lx1 * v11[e]);
+                    if (a_pix[j] < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
                 a_reg[j] = v;
             }
@@ -449,15 +455,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             if (it_cs >= seg_cn) {
                 it_cs = 0;
                 ++it_seg;
-                if (it_seg >= p.nseg) {
+                if (it_seg >= nseg) {
                     it_seg = 0;
                     ++it_kx;
-                    if (it_kx >= p.KW) {
+                    if (it_kx >= kw_n) {
                         it_kx = 0;
                         ++it_ky;
                     }
                     tap_setup();
                 }
+                // (keeping the three descriptors in extra locals instead of re-reading kernarg memory here makes
+                // hipcc spill the whole loop state to scratch -- measured, ROCm 7.2 -- and a segment switch only
+                // happens every few stages)
                 seg_base = sel3(p.in, it_seg) + (long)b * (it_seg == 0 ? p.seg_bs[0] : (it_seg == 1 ? p.seg_bs[1] : p.seg_bs[2]));
                 seg_ld = it_seg == 0 ? p.seg_ld[0] : (it_seg == 1 ? p.seg_ld[1] : p.seg_ld[2]);
                 seg_cn = it_seg == 0 ? p.seg_c[0] : (it_seg == 1 ? p.seg_c[1] : p.seg_c[2]);
@@ -465,9 +474,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         }
     };
 
-    auto store_chunk = [&](int buf) {
+    auto store_chunk = [&](int buf) __attribute__((always_inline)) {
         float* sA = smem + buf * STAGE;
         float* sB = sA + BM * LS;
+#pragma unroll
+        for (int j = 0; j < A_IT; ++j)
+            if (a_zero[j]) a_reg[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it)
+            if (!b_ok[it]) b_reg[it] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (PREC == 0) {
 #pragma unroll
             for (int j = 0; j < A_IT; ++j)
