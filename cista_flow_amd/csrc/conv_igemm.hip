@@ -26,6 +26,7 @@ namespace cf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
@@ -51,6 +52,21 @@ __device__ __forceinline__ void split_f16(const f32x4& v, f16x4& hi, f16x4& lo) 
         hi[e] = h;
         lo[e] = (_Float16)(x - (float)h);
     }
+}
+
+// Global reads go through raw buffer loads: a wave-uniform descriptor (SGPRs) + a 32-bit per-lane byte offset
+// instead of 64-bit flat addresses (far fewer VALU ops per load), and the hardware range check returns 0 for
+// BUF_OOB offsets -- which is how zero padding and out-of-tile rows are produced, with no select afterwards.
+static constexpr unsigned BUF_RECORDS = 0x7FFFFF00u;
+static constexpr unsigned BUF_OOB = 0x7FFFFF80u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, BUF_RECORDS, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 
 __device__ __forceinline__ const float* sel3(const float* const (&a)[3], int s) {
@@ -230,6 +246,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     constexpr int B_IT = (BN * QPR + 255) / 256;
     constexpr int STAGE = (BM + BN) * LS;
     constexpr int GTAB = (AMODE == A_GATHER) ? 256 : 4;
+    constexpr bool A_FULL = (BM * QPR) % 256 == 0;   // every staging slot of every thread is inside the tile
+    constexpr bool B_FULL = (BN * QPR) % 256 == 0;
     constexpr int RED = (WK - 1) * WMN * TM * TN * 1024;            // split-K reduction area (floats)
     constexpr int SMEM = (2 * STAGE > RED + WMN * 32 * EPI_S) ? 2 * STAGE : RED + WMN * 32 * EPI_S;
 
@@ -288,22 +306,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         a_oy[j] = oy * p.stride - p.padT;
         a_ox[j] = (m - oy * p.Wo) * p.stride - p.padL;
     }
-    // per-thread B slots
-    const float* b_ptr[B_IT];
-    bool b_ok[B_IT], b_live[B_IT];
+    // per-thread B slots: byte offset of (row, quad) inside the packed matrix, BUF_OOB past its last row
+    unsigned b_off[B_IT];
+    bool b_live[B_IT];
     int b_row[B_IT], b_q[B_IT];
-    {
-        const float* wbase = p.w + (long)b * p.w_bs;
+    const __amdgpu_buffer_rsrc_t b_rsrc = make_rsrc(p.w + (long)b * p.w_bs);
 #pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            const int slot = tid + 256 * it;
-            const int row = slot / QPR;
-            b_row[it] = row;
-            b_q[it] = slot - row * QPR;
-            b_live[it] = row < BN;
-            b_ok[it] = b_live[it] && (n0 + row) < p.w_rows;
-            b_ptr[it] = wbase + (long)(b_ok[it] ? (n0 + row) : 0) * p.Ktot + b_q[it] * 4;
-        }
+    for (int it = 0; it < B_IT; ++it) {
+        const int slot = tid + 256 * it;
+        const int row = slot / QPR;
+        b_row[it] = row;
+        b_q[it] = slot - row * QPR;
+        b_live[it] = row < BN;
+        const bool ok = b_live[it] && (n0 + row) < p.w_rows;
+        b_off[it] = ok ? (unsigned)(n0 + row) * (unsigned)p.Ktot * 4u + (unsigned)b_q[it] * 16u : BUF_OOB;
     }
     if (AMODE == A_GATHER) {
         const int ntap = p.KH * p.KW;
@@ -373,9 +389,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     if (AMODE != A_GATHER) tap_setup();
 
     f32x4 a_reg[A_IT], b_reg[B_IT];
-    bool a_zero[A_IT];
-#pragma unroll
-    for (int j = 0; j < A_IT; ++j) a_zero[j] = false;
 
     auto load_chunk = [&]() __attribute__((always_inline)) {
         // ---- B: packed weights, K contiguous ----
@@ -383,11 +396,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         for (int it = 0; it < B_IT; ++it) {
             // unconditional load (rows past the matrix were redirected to row 0) + select: a branch around the
             // load would serialise the wave and drain vmcnt per element
-            b_reg[it] = *reinterpret_cast<const f32x4*>(b_ptr[it] + it_k);   // zeroed at store time if !b_ok
+            b_reg[it] = buf_load4(b_rsrc, b_off[it], (unsigned)it_k * 4u);
         }
         // ---- A ----
         if (AMODE == A_GATHER) {
-            const float* src = seg_base;
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(seg_base);
 #pragma unroll
             for (int j = 0; j < A_IT; ++j) {
                 const int4 tb = *reinterpret_cast<const int4*>(&gtab[it_k + a_q[j] * 4]);
@@ -409,7 +422,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                     const int sy = iy - p.g_offy;
                     const int sx = ix - p.g_offx;
                     ok = ok && sy >= 0 && sx >= 0;
-                    float x = src[ok ? (c * p.Hsrc + sy) * p.Wsrc + sx : 0];
+                    float x = buf_load1(rs, ok ? (unsigned)((c * p.Hsrc + sy) * p.Wsrc + sx) * 4u : BUF_OOB, 0u);
                     x = x * p.g_scale + p.g_shift;
                     if (p.g_subgrid) x -= (c == 0) ? (float)sx : (float)sy;
                     v[e] = ok ? x : 0.f;
@@ -417,34 +430,31 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                 a_reg[j] = v;
             }
         } else if (AMODE == A_NHWC) {
-            const float* src = seg_base + it_cs;
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(seg_base);
+            const unsigned ld4 = (unsigned)seg_ld * 4u, so = (unsigned)it_cs * 4u;
 #pragma unroll
             for (int j = 0; j < A_IT; ++j) {
-                // padding taps read pixel 0; the zeroing happens at LDS-store time (a_zero) so that the loaded
-                // value is not touched -- and hence not waited for -- before this chunk's MFMAs
-                const int pix = a_pix[j] < 0 ? 0 : a_pix[j];
-                a_zero[j] = a_pix[j] < 0;
-                a_reg[j] = *reinterpret_cast<const f32x4*>(src + (long)pix * seg_ld + a_q[j] * 4);
+                // padding taps / rows past the image use an out-of-range offset: the load returns zeros
+                const unsigned off = a_pix[j] < 0 ? BUF_OOB : (unsigned)a_pix[j] * ld4 + (unsigned)a_q[j] * 16u;
+                a_reg[j] = buf_load4(rs, off, so);
             }
         } else {
-            const float* src = seg_base + it_cs;
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(seg_base);
+            const unsigned ld4 = (unsigned)seg_ld * 4u, so = (unsigned)it_cs * 4u;
 #pragma unroll
             for (int j = 0; j < A_IT; ++j) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                {
-                    const int qo = a_q[j] * 4;
-                    const int p00 = a_pix[j] < 0 ? 0 : a_pix[j];
-                    const f32x4 v00 = *reinterpret_cast<const f32x4*>(src + (long)p00 * seg_ld + qo);
-                    const f32x4 v01 = *reinterpret_cast<const f32x4*>(src + (long)u_p01[j] * seg_ld + qo);
-                    const f32x4 v10 = *reinterpret_cast<const f32x4*>(src + (long)u_p10[j] * seg_ld + qo);
-                    const f32x4 v11 = *reinterpret_cast<const f32x4*>(src + (long)u_p11[j] * seg_ld + qo);
-                    const float ly1 = u_ly1[j], lx1 = u_lx1[j];
-                    const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+                const bool inv = a_pix[j] < 0;          // all four taps out of range -> zeros -> lerp gives 0
+                const unsigned qo = (unsigned)a_q[j] * 16u;
+                const f32x4 v00 = buf_load4(rs, inv ? BUF_OOB : (unsigned)a_pix[j] * ld4 + qo, so);
+                const f32x4 v01 = buf_load4(rs, inv ? BUF_OOB : (unsigned)u_p01[j] * ld4 + qo, so);
+                const f32x4 v10 = buf_load4(rs, inv ? BUF_OOB : (unsigned)u_p10[j] * ld4 + qo, so);
+                const f32x4 v11 = buf_load4(rs, inv ? BUF_OOB : (unsigned)u_p11[j] * ld4 + qo, so);
+                const float ly1 = u_ly1[j], lx1 = u_lx1[j];
+                const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+                f32x4 v;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        v[e] = ly0 * (lx0 * v00[e] + lx1 * v01[e]) + ly1 * (lx0 * v10[e] + lx1 * v11[e]);
-                    if (a_pix[j] < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
+                for (int e = 0; e < 4; ++e)
+                    v[e] = ly0 * (lx0 * v00[e] + lx1 * v01[e]) + ly1 * (lx0 * v10[e] + lx1 * v11[e]);
                 a_reg[j] = v;
             }
         }
@@ -477,24 +487,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     auto store_chunk = [&](int buf) __attribute__((always_inline)) {
         float* sA = smem + buf * STAGE;
         float* sB = sA + BM * LS;
-#pragma unroll
-        for (int j = 0; j < A_IT; ++j)
-            if (a_zero[j]) a_reg[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it)
-            if (!b_ok[it]) b_reg[it] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (PREC == 0) {
 #pragma unroll
             for (int j = 0; j < A_IT; ++j)
-                if (a_live[j]) *reinterpret_cast<f32x4*>(sA + a_row[j] * LS + a_q[j] * 4) = a_reg[j];
+                if (A_FULL || a_live[j]) *reinterpret_cast<f32x4*>(sA + a_row[j] * LS + a_q[j] * 4) = a_reg[j];
 #pragma unroll
             for (int it = 0; it < B_IT; ++it)
-                if (b_live[it]) *reinterpret_cast<f32x4*>(sB + b_row[it] * LS + b_q[it] * 4) = b_reg[it];
+                if (B_FULL || b_live[it]) *reinterpret_cast<f32x4*>(sB + b_row[it] * LS + b_q[it] * 4) = b_reg[it];
         } else {
             // quad q of a row = k 4q..4q+3 -> chunk q/4: hi at chunk*64 + (q%4)*8 bytes, lo 32 bytes further
 #pragma unroll
             for (int j = 0; j < A_IT; ++j) {
-                if (!a_live[j]) continue;
+                if (!A_FULL && !a_live[j]) continue;
                 f16x4 hi, lo;
                 split_f16(a_reg[j], hi, lo);
                 char* dst = reinterpret_cast<char*>(sA + a_row[j] * LS) + (a_q[j] >> 2) * 64 + (a_q[j] & 3) * 8;
@@ -503,7 +507,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             }
 #pragma unroll
             for (int it = 0; it < B_IT; ++it) {
-                if (!b_live[it]) continue;
+                if (!B_FULL && !b_live[it]) continue;
                 if (p.b_f32) {   // B operand is an activation (all-pairs correlation): split it here as well
                     f16x4 hi, lo;
                     split_f16(b_reg[it], hi, lo);
