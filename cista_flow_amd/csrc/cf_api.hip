@@ -654,7 +654,7 @@ extern "C" int cf_profile_enable(cf_handle* h, int on) {
 // Synchronises the recorded events, then for tile kind t = 1..6 (conv_igemm.hip) accumulates
 // ms[t] (sum of launch durations), flops[t] (sum of algorithmic flops), count[t]; index 0 = totals.
 extern "C" int cf_profile_read(cf_handle* h, double* ms, double* flops, long long* count, int n) {
-    if (!h || !ms || !flops || !count || n < 8) return CF_ERR_ARG;
+    if (!h || !ms || !flops || !count || n < 16) return CF_ERR_ARG;
     for (int i = 0; i < n; ++i) { ms[i] = 0; flops[i] = 0; count[i] = 0; }
     struct Agg { double ms = 0, flops = 0; long cnt = 0; int tile = 0; };
     std::map<std::string, Agg> agg;

@@ -231,12 +231,16 @@ __device__ __forceinline__ void epilogue4(const ConvParams& p, int b, int m, int
 //       1 = plain f16 operands, one MFMA (the reduced-precision mode BASELINE configs[4] names).
 // In the f16 modes an LDS row holds, per 16-column chunk, [16 x hi | 16 x lo] (64 bytes): the same bytes as
 // 16 fp32, so tile geometry, strides and the pre-split weight copies (same format in HBM) are shared.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int WK, int AMODE, int PREC>
+// KCW: k-columns one wave consumes per stage (16 or 32).  32 doubles the MFMA work between two barriers, which
+// is what the small tiles need (their fixed per-stage cost -- iterator, waits, barrier -- rivals 8 MFMAs).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int WK, int AMODE, int PREC, int KCW = 16>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+    static_assert(KCW == 16 || KCW == 32, "KCW");
+    static_assert(KCW == 16 || AMODE == A_NHWC, "wide stages only for the plain NHWC read");
     static_assert(WAVES_M * WAVES_N * WK == 4, "4 waves per workgroup");
     static_assert(BM % 32 == 0 && BN % 32 == 0, "tiles are multiples of the 32x32 MFMA");
     static_assert(AMODE == A_NHWC || WK == 1, "split-K tiles only for the plain NHWC read");
-    constexpr int KS = KC * WK;          // k-columns per stage
+    constexpr int KS = KCW * WK;         // k-columns per stage
     constexpr int QPR = KS / 4;          // 16-byte quads per row
     constexpr int LS = KS + 4;           // LDS row stride (floats): 16-byte slot (LS/4)*r mod 16 is a permutation
     constexpr int WMN = WAVES_M * WAVES_N;
@@ -530,20 +534,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     for (int ck = 0; ck < nck; ++ck) {
         const int buf = ck & 1;
         if (ck + 1 < nck) load_chunk();
-        const float* sA = smem + buf * STAGE + wk * KC;
-        const float* sB = smem + buf * STAGE + BM * LS + wk * KC;
+        const float* sA = smem + buf * STAGE + wk * KCW;
+        const float* sB = smem + buf * STAGE + BM * LS + wk * KCW;
         if (PREC != 0) {
-            // one v_mfma_f32_32x32x16_f16 spans the whole 16-column chunk: lane (r, h) holds k = 8h..8h+7
+#pragma unroll
+          for (int cc = 0; cc < KCW / 16; ++cc) {
+            // one v_mfma_f32_32x32x16_f16 spans a whole 16-column chunk: lane (r, h) holds k = 8h..8h+7
             f16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const char* r = reinterpret_cast<const char*>(sA + ((wm * TM + i) * 32 + lr) * LS) + lh * 16;
+                const char* r = reinterpret_cast<const char*>(sA + ((wm * TM + i) * 32 + lr) * LS) + cc * 64 + lh * 16;
                 ah[i] = *reinterpret_cast<const f16x8*>(r);
                 if (PREC == 3) al[i] = *reinterpret_cast<const f16x8*>(r + 32);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const char* r = reinterpret_cast<const char*>(sB + ((wn * TN + j) * 32 + lr) * LS) + lh * 16;
+                const char* r = reinterpret_cast<const char*>(sB + ((wn * TN + j) * 32 + lr) * LS) + cc * 64 + lh * 16;
                 bh[j] = *reinterpret_cast<const f16x8*>(r);
                 if (PREC == 3) bl[j] = *reinterpret_cast<const f16x8*>(r + 32);
             }
@@ -557,9 +563,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                     }
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
+          }
         } else
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < KCW / 8; ++ks) {
             f32x4 af[TM], bf[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -634,13 +641,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, int WK, int PREC>
+template <int BM, int BN, int WM, int WN, int WK, int PREC, int KCW = 16>
 static hipError_t launch_tp(const ConvParams& p, int batch, hipStream_t s) {
     const int M = p.Ho * p.Wo;
     dim3 grid(((M + BM - 1) / BM) * ((p.cout + BN - 1) / BN) * batch);
     if (p.a_mode == A_NHWC) {
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, WK, A_NHWC, PREC>), grid, dim3(256), 0, s, p);
-    } else if constexpr (WK == 1) {
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, WK, A_NHWC, PREC, KCW>), grid, dim3(256), 0, s, p);
+    } else if constexpr (WK == 1 && KCW == 16) {
         if (p.a_mode == A_UPS2X) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1, A_UPS2X, PREC>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1, A_GATHER, PREC>), grid, dim3(256), 0, s, p);
     } else {
@@ -649,21 +656,21 @@ static hipError_t launch_tp(const ConvParams& p, int batch, hipStream_t s) {
     return hipGetLastError();
 }
 
-template <int BM, int BN, int WM, int WN, int WK>
+template <int BM, int BN, int WM, int WN, int WK, int KCW = 16>
 static hipError_t launch_t(const ConvParams& p, int batch, hipStream_t s) {
-    if (p.prec == 3) return launch_tp<BM, BN, WM, WN, WK, 3>(p, batch, s);
-    if (p.prec == 1) return launch_tp<BM, BN, WM, WN, WK, 1>(p, batch, s);
-    return launch_tp<BM, BN, WM, WN, WK, 0>(p, batch, s);
+    if (p.prec == 3) return launch_tp<BM, BN, WM, WN, WK, 3, KCW>(p, batch, s);
+    if (p.prec == 1) return launch_tp<BM, BN, WM, WN, WK, 1, KCW>(p, batch, s);
+    return launch_tp<BM, BN, WM, WN, WK, 0, KCW>(p, batch, s);
 }
 
-// split-K tiles need every channel segment to be a whole number of stages
-static bool splitk_ok(const ConvParams& p, int wk) {
+// stages wider than 16 columns need every channel segment to be a whole number of stages
+static bool stage_ok(const ConvParams& p, int ks) {
     if (p.a_mode != A_NHWC) return false;
-    const int ks = KC * wk;
     for (int i = 0; i < p.nseg; ++i)
         if (p.seg_c[i] % ks) return false;
     return true;
 }
+static bool splitk_ok(const ConvParams& p, int wk) { return stage_ok(p, KC * wk); }
 
 // tile ids: 1 = 128x128, 2 = 128x64, 3 = 128x96, 4 = 64x64, 5 = 64x128, 6 = 128x32
 // ---------------------------------------------------------------------------
@@ -758,6 +765,11 @@ const char* conv_tile_name(int tile) {
         case 7: return "conv_smalln_kernel";
         case 8: return "conv_igemm_kernel<32,32,1,1,4>";
         case 9: return "conv_igemm_kernel<32,64,1,2,2>";
+        case 10: return "conv_igemm_kernel<32,64,1,2,2,kcw32>";
+        case 11: return "conv_igemm_kernel<32,32,1,1,4,kcw32>";
+        case 12: return "conv_igemm_kernel<64,64,2,2,1,kcw32>";
+        case 13: return "conv_igemm_kernel<128,128,2,2,1,kcw32>";
+        case 14: return "conv_igemm_kernel<128,64,2,2,1,kcw32>";
         default: return "?";
     }
 }
@@ -804,6 +816,7 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
     if ((p.Ho - 1) * p.stride - p.padT + 0 >= p.Hin || (p.Wo - 1) * p.stride - p.padL >= p.Win)
         return hipErrorInvalidValue;
 
+    const bool auto_tile = tile == 0;
     if (tile == 0 && smalln_ok(p)) tile = 7;
     if (tile == 7) {
         if (!smalln_ok(p)) return hipErrorInvalidValue;
@@ -834,6 +847,13 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
             else tile = splitk_ok(p, 4) ? 8 : (splitk_ok(p, 2) ? 9 : 4);
         }
     }
+    if (tile == 0) return hipErrorInvalidValue;
+    if (auto_tile) {
+        // wide stages (32 k-columns per wave between barriers) measured 3-8 % faster wherever the channel
+        // segments allow them (tools/conv_bench.py, MI355X)
+        if (tile == 9 && stage_ok(p, 64)) tile = 10;
+        else if (tile == 4 && stage_ok(p, 32)) tile = 12;
+    }
     if (tile_used) *tile_used = tile;
     if (p.prec != 0 && p.prec != 1 && p.prec != 3) return hipErrorInvalidValue;
     if (p.prec != 0) {          // f16 modes: pre-split weights when there are some, else split B while staging
@@ -853,6 +873,11 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
         case 6: return launch_t<128, 32, 4, 1, 1>(p, batch, s);
         case 8: return splitk_ok(p, 4) ? launch_t<32, 32, 1, 1, 4>(p, batch, s) : hipErrorInvalidValue;
         case 9: return splitk_ok(p, 2) ? launch_t<32, 64, 1, 2, 2>(p, batch, s) : hipErrorInvalidValue;
+        case 10: return stage_ok(p, 64) ? launch_t<32, 64, 1, 2, 2, 32>(p, batch, s) : hipErrorInvalidValue;
+        case 11: return stage_ok(p, 128) ? launch_t<32, 32, 1, 1, 4, 32>(p, batch, s) : hipErrorInvalidValue;
+        case 12: return stage_ok(p, 32) ? launch_t<64, 64, 2, 2, 1, 32>(p, batch, s) : hipErrorInvalidValue;
+        case 13: return stage_ok(p, 32) ? launch_t<128, 128, 2, 2, 1, 32>(p, batch, s) : hipErrorInvalidValue;
+        case 14: return stage_ok(p, 32) ? launch_t<128, 64, 2, 2, 1, 32>(p, batch, s) : hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }
 }

@@ -85,6 +85,11 @@ CONV_CASES = [
     (128, 256, 3, 3, 1, 1, 1, 0, 9),
     (96, 96, 3, 3, 2, 1, 1, 0, 9),
     (384, 128, 5, 1, 1, 2, 0, 0, 9),
+    (128, 256, 3, 3, 1, 1, 1, 0, 10),  # wide-stage (32 k-columns per wave) variants
+    (256, 128, 1, 5, 1, 0, 2, 0, 11),
+    (96, 96, 3, 3, 1, 1, 1, 0, 12),
+    (192, 256, 3, 3, 1, 1, 1, 1, 13),
+    (128, 64, 3, 3, 2, 1, 1, 1, 14),
 ]
 
 
@@ -297,7 +302,7 @@ def test_events_to_voxel_gpu(gpu):
 
 @pytest.mark.parametrize("prec,tol", [(3, 2e-5), (1, 4e-3)])
 @pytest.mark.parametrize("case", [(192, 256, 3, 1, 1, 0), (128, 64, 3, 1, 1, 4), (384, 128, 3, 1, 1, 9), (64, 64, 3, 2, 1, 2),
-                                  (128, 128, 3, 1, 0, 8)])
+                                  (128, 128, 3, 1, 0, 8), (128, 256, 3, 1, 0, 10), (256, 128, 3, 1, 0, 11), (64, 128, 3, 1, 1, 13)])
 def test_conv_f16_split_modes(gpu, case, prec, tol):
     """precision 3 (f16x3 split MFMA) must stay fp32-grade; precision 1 (plain f16 products) is the reduced mode."""
     L, lib = _lib()

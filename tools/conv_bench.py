@@ -52,7 +52,7 @@ def run(shape, tile, iters=20):
 
 
 def main():
-    tiles = [int(t) for t in os.environ.get("TILES", "0,2,4,8,9").split(",")]
+    tiles = [int(t) for t in os.environ.get("TILES", "0,1,2,4,8,9,10,11,12,13,14").split(",")]
     for sh in SHAPES:
         res = []
         for t in tiles:
