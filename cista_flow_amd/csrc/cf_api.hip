@@ -112,6 +112,7 @@ struct cf_handle {
     const char* tag = "";
     std::string prof_report;
     bool prof = false;
+    bool serial = false;   // measurement mode: no side-stream concurrency
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> prof_pool;
     hipEvent_t prof_event() {
@@ -648,6 +649,7 @@ extern "C" size_t cf_workspace_bytes(const cf_handle* h) { return h ? h->arena.c
 extern "C" int cf_profile_enable(cf_handle* h, int on) {
     if (!h) return CF_ERR_ARG;
     h->prof = on != 0;
+    h->serial = on != 0;
     return CF_OK;
 }
 
@@ -896,29 +898,33 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
     const int FLO = eraft ? 192 : 256;       // channel offset of the flow branch inside it
     const int bins = h->cfg.num_bins;
     int rc;
+    // side streams; in measurement mode (cf_profile_enable) everything is serialised on the caller's stream so
+    // that every kernel's HIP-event duration is that kernel alone on the chip
+    hipStream_t sx0 = h->serial ? st : sx0;
+    hipStream_t sx1 = h->serial ? st : sx1;
     // encoders: emap = enet(pad(ev)); fmap1 = fnet(pad(2*I-1)); cnet(pad(2*I-1)) -> net, inp.
     // The three encoders are independent and individually too small to fill 256 CUs at 1/4 and 1/8
     // resolution, so they run concurrently: enet on the caller's stream, fnet / cnet on the side streams.
     CF_HIP(h, hipEventRecord(h->ev_fork, st));
-    CF_HIP(h, hipStreamWaitEvent(h->aux[0], h->ev_fork, 0));
-    CF_HIP(h, hipStreamWaitEvent(h->aux[1], h->ev_fork, 0));
+    CF_HIP(h, hipStreamWaitEvent(sx0, h->ev_fork, 0));
+    CF_HIP(h, hipStreamWaitEvent(sx1, h->ev_fork, 0));
     if (!eraft) {
         if ((rc = encoder_forward(h, "event_flownet.enet", false, ev, bins, 1.f, 0.f, h->emap, nullptr, 0, st))) return rc;
-        if ((rc = encoder_forward(h, "event_flownet.fnet", false, img, 1, 2.f, -1.f, h->fmap1, nullptr, 1, h->aux[0]))) return rc;
-        if ((rc = encoder_forward(h, "event_flownet.cnet", true, img, 1, 2.f, -1.f, h->net, h->inp, 2, h->aux[1]))) return rc;
+        if ((rc = encoder_forward(h, "event_flownet.fnet", false, img, 1, 2.f, -1.f, h->fmap1, nullptr, 1, sx0))) return rc;
+        if ((rc = encoder_forward(h, "event_flownet.cnet", true, img, 1, 2.f, -1.f, h->net, h->inp, 2, sx1))) return rc;
     } else {
         if ((rc = encoder_forward(h, "event_flownet.fnet", false, ev, bins, 1.f, 0.f, h->fmap1, nullptr, 0, st))) return rc;
-        if ((rc = encoder_forward(h, "event_flownet.fnet", false, img, bins, 1.f, 0.f, h->pfmap2, nullptr, 1, h->aux[0]))) return rc;
-        if ((rc = encoder_forward(h, "event_flownet.cnet", true, img, bins, 1.f, 0.f, h->net, h->inp, 2, h->aux[1]))) return rc;
+        if ((rc = encoder_forward(h, "event_flownet.fnet", false, img, bins, 1.f, 0.f, h->pfmap2, nullptr, 1, sx0))) return rc;
+        if ((rc = encoder_forward(h, "event_flownet.cnet", true, img, bins, 1.f, 0.f, h->net, h->inp, 2, sx1))) return rc;
     }
     // cnet-only consumers stay on its stream: iteration-invariant `inp` part of the six GRU convolutions
     for (int pass = 0; pass < 2; ++pass) {
         const int pT = pass == 0 ? 0 : 2, pL = pass == 0 ? 2 : 0;
         ConvParams g = nhwc_conv(h->conv[pass == 0 ? "gru.pre1" : "gru.pre2"], {{h->inp, 128, 128, N * 128}}, h8, w8, h8, w8, 1, pT, pL, 0, h->gpre[pass], 384, N * 384, EPI_NONE);
-        CF_HIP(h, run_conv(h, g, B, h->aux[1]));
+        CF_HIP(h, run_conv(h, g, B, sx1));
     }
-    CF_HIP(h, hipEventRecord(h->ev_join[0], h->aux[0]));
-    CF_HIP(h, hipEventRecord(h->ev_join[1], h->aux[1]));
+    CF_HIP(h, hipEventRecord(h->ev_join[0], sx0));
+    CF_HIP(h, hipEventRecord(h->ev_join[1], sx1));
     // emap-only consumers overlap with the tail of fnet / cnet (with_event_updater.py:105-106 is
     // iteration-invariant)
     if (!eraft) {
@@ -968,13 +974,13 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
         // BasicMotionEncoder  with_event_updater.py:102-112.  The flow branch (convf1 -> convf2) only needs
         // coords1, so it runs on a side stream next to lookup -> convc1 -> convc2.
         CF_HIP(h, hipEventRecord(h->ev_fork, st));
-        CF_HIP(h, hipStreamWaitEvent(h->aux[0], h->ev_fork, 0));
+        CF_HIP(h, hipStreamWaitEvent(sx0, h->ev_fork, 0));
         {
             ConvParams f1 = gather_conv(h->conv["convf1"], h->coords1, 2, h8, w8, 0, 0, 1.f, 0.f, 1, h8, w8, 1, 3, 3, 0, h->f1buf, 128, N * 128, EPI_RELU);
-            CF_HIP(h, run_conv(h, f1, B, h->aux[0]));
+            CF_HIP(h, run_conv(h, f1, B, sx0));
             ConvParams f2 = nhwc_conv(h->conv["convf2"], {{h->f1buf, 128, 128, N * 128}}, h8, w8, h8, w8, 1, 1, 1, 0, h->mcat + FLO, MC, N * MC, EPI_RELU);
-            CF_HIP(h, run_conv(h, f2, B, h->aux[0]));
-            CF_HIP(h, hipEventRecord(h->ev_join[0], h->aux[0]));
+            CF_HIP(h, run_conv(h, f2, B, sx0));
+            CF_HIP(h, hipEventRecord(h->ev_join[0], sx0));
         }
         ConvParams c1 = nhwc_conv(h->conv["convc1"], {{h->corrfeat, cf_handle::CORR_LD, cf_handle::CORR_LD, N * cf_handle::CORR_LD}}, h8, w8, h8, w8, 1, 0, 0, 0, h->c1buf, 256, N * 256, EPI_RELU);
         CF_HIP(h, run_conv(h, c1, B, st));

@@ -109,7 +109,8 @@ int cf_events_to_voxel(const double* events, const int64_t* offsets, int B, int 
                        double* stats_scratch, int normalize, void* stream);
 
 /* measurement: when enabled, every convolution launch of the fused paths is bracketed by HIP events on
- * the launch stream.  cf_profile_read synchronises them and returns, for conv tile kind t = 1..6
+ * the launch stream and the library's side streams are folded into the caller's stream (kernels run one at
+ * a time, so a duration is that kernel alone on the chip -- what a roofline fraction needs).  cf_profile_read synchronises them and returns, for conv tile kind t = 1..6
  * (index 0 = all), the summed launch duration in ms, the summed algorithmic flops (2*M*N*K with the
  * un-padded K) and the launch count, then clears the records.  cf_conv_tile_name(t) = kernel symbol. */
 int cf_profile_enable(cf_handle* h, int on);
