@@ -22,9 +22,10 @@ def per_kernel(d, counter):
             if r["Counter_Name"] != counter:
                 continue
             n = r["Kernel_Name"]
-            m = re.match(r"void cf::(conv_igemm_kernel)<(\d+), (\d+), (\d+), (\d+), (\d+), \d+>", n)
-            if m:
-                n = "%s<%s,%s,%s,%s,%s>" % m.groups()
+            m = re.match(r"void cf::(conv_igemm_kernel)<(\d+), (\d+), (\d+), (\d+), (\d+), \d+, \d+, (\d+)>", n)
+            if m:   # fold the A-mode / precision instantiations of one tile shape together (bench.py's names)
+                g = m.groups()
+                n = "%s<%s,%s,%s,%s,%s%s>" % (g[0], g[1], g[2], g[3], g[4], g[5], ",kcw32" if g[6] == "32" else "")
             else:
                 n = re.sub(r"^void ", "", n).split("(")[0].replace("cf::", "")
                 n = re.sub(r"<.*>", "", n) if n.startswith("conv_smalln") else n
