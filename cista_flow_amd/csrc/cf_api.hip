@@ -138,9 +138,33 @@ struct cf_handle {
 
 // every convolution of the graphs goes through here (optional HIP-event bracketing)
 #define TAG(h, t) ((h)->tag = (t))
+// tuning hook: CF_TILE_OVERRIDE="cista.P=23,gru.zr1=20" forces a tile kind for the named layers (tools only)
+static int tile_override(const char* tag) {
+    static std::map<std::string, int>* m = nullptr;
+    if (!m) {
+        m = new std::map<std::string, int>();
+        if (const char* e = getenv("CF_TILE_OVERRIDE")) {
+            std::string s(e);
+            size_t pos = 0;
+            while (pos < s.size()) {
+                size_t c = s.find(',', pos);
+                if (c == std::string::npos) c = s.size();
+                const std::string item = s.substr(pos, c - pos);
+                const size_t eq = item.find('=');
+                if (eq != std::string::npos) (*m)[item.substr(0, eq)] = atoi(item.c_str() + eq + 1);
+                pos = c + 1;
+            }
+        }
+    }
+    if (m->empty() || !tag) return 0;
+    auto it = m->find(tag);
+    return it == m->end() ? 0 : it->second;
+}
+
 static hipError_t run_conv(cf_handle* h, const ConvParams& p_in, int batch, hipStream_t st, int tile = 0) {
     ConvParams p = p_in;
     p.prec = h ? h->cfg.precision : 0;
+    if (tile == 0) tile = tile_override(p.tag ? p.tag : (h ? h->tag : nullptr));
     if (!h || !h->prof) return launch_conv(p, batch, st, tile);
     cf_handle::ProfRec r;
     r.a = h->prof_event();
@@ -653,7 +677,7 @@ extern "C" int cf_profile_enable(cf_handle* h, int on) {
     return CF_OK;
 }
 
-// Synchronises the recorded events, then for tile kind t = 1..6 (conv_igemm.hip) accumulates
+// Synchronises the recorded events, then for tile kind t = 1..n-1 (conv_igemm.hip: conv_tile_name) accumulates
 // ms[t] (sum of launch durations), flops[t] (sum of algorithmic flops), count[t]; index 0 = totals.
 extern "C" int cf_profile_read(cf_handle* h, double* ms, double* flops, long long* count, int n) {
     if (!h || !ms || !flops || !count || n < 16) return CF_ERR_ARG;
@@ -900,8 +924,8 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
     int rc;
     // side streams; in measurement mode (cf_profile_enable) everything is serialised on the caller's stream so
     // that every kernel's HIP-event duration is that kernel alone on the chip
-    hipStream_t sx0 = h->serial ? st : sx0;
-    hipStream_t sx1 = h->serial ? st : sx1;
+    hipStream_t sx0 = h->serial ? st : h->aux[0];
+    hipStream_t sx1 = h->serial ? st : h->aux[1];
     // encoders: emap = enet(pad(ev)); fmap1 = fnet(pad(2*I-1)); cnet(pad(2*I-1)) -> net, inp.
     // The three encoders are independent and individually too small to fill 256 CUs at 1/4 and 1/8
     // resolution, so they run concurrently: enet on the caller's stream, fnet / cnet on the side streams.

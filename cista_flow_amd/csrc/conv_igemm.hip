@@ -31,7 +31,6 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 static constexpr int KC = 16;      // K chunk (floats)
-static constexpr int LDS_S = 20;   // LDS row stride (floats)
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
@@ -672,6 +671,310 @@ static bool stage_ok(const ConvParams& p, int ks) {
 }
 static bool splitk_ok(const ConvParams& p, int wk) { return stage_ok(p, KC * wk); }
 
+// ---------------------------------------------------------------------------------------------------------
+// LDS-DMA variant (plain NHWC read, fp32 MFMA): the A / B stage tiles are written straight into LDS by
+// `buffer_load_dwordx4 ... lds` -- no staging registers, no ds_write pass, no per-stage vmcnt(0) -- through a
+// 3-deep ring with a COUNTED vmcnt (the DMA of stages k+1 / k+2 stays in flight across the one barrier per
+// stage).  A wave-instruction lands 64 x 16 bytes LINEARLY in LDS (lane i -> base + 16 i), so rows are unpadded
+// and bank conflicts are avoided by an XOR swizzle applied on the SOURCE side (which 16-byte quad of its row a
+// lane fetches) and again when the fragments are read: slot(row, q) = row*QPR + (q ^ (row / RPB) % QPR), with
+// RPB = rows per 256-byte bank row.  Out-of-range offsets (zero padding, rows past the tile) make the DMA write
+// zeros.  Hand-off rule: wait vmcnt(loads of one stage) -> s_barrier -> issue stage k+2 -> read stage k.
+// ---------------------------------------------------------------------------------------------------------
+// helpers of the LDS-DMA kernel (kept out of the __global__ body: the host pass has no such builtins)
+__device__ __forceinline__ void dma16_to_lds(__amdgpu_buffer_rsrc_t rs, float* lds_dst, unsigned voff, unsigned soff) {
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)lds_dst, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ void wait_vmcnt_le(int n) {   // n is wave-uniform, <= 8
+    switch (n) {
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+__device__ __forceinline__ void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void raw_barrier() {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int WK, int KCW>
+__global__ __launch_bounds__(256) void conv_dma_kernel(const ConvParams p) {
+    static_assert(WAVES_M * WAVES_N * WK == 4, "4 waves per workgroup");
+    constexpr int KS = KCW * WK;
+    constexpr int QPR = KS / 4;                        // 16-byte quads per row
+    constexpr int RPB = (16 / QPR) > 0 ? (16 / QPR) : 1;   // rows per 256-byte bank row
+    constexpr int WMN = WAVES_M * WAVES_N;
+    constexpr int TM = BM / (32 * WAVES_M);
+    constexpr int TN = BN / (32 * WAVES_N);
+    constexpr int A_SLOTS = BM * QPR, B_SLOTS = BN * QPR;
+    static_assert(A_SLOTS % 64 == 0 && B_SLOTS % 64 == 0, "whole wave-instructions");
+    constexpr int A_IT = (A_SLOTS + 255) / 256;
+    constexpr int B_IT = (B_SLOTS + 255) / 256;
+    constexpr int STAGE = (BM + BN) * KS;              // floats per ring slot
+    constexpr int NBUF = 3;
+    constexpr int RED = (WK - 1) * WMN * TM * TN * 1024;
+    constexpr int SMEM = (NBUF * STAGE > RED + WMN * 32 * EPI_S) ? NBUF * STAGE : RED + WMN * 32 * EPI_S;
+
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wk = wave / WMN;
+    const int wmn = wave % WMN;
+    const int wm = wmn / WAVES_N;
+    const int wn = wmn % WAVES_N;
+    const int M = p.Ho * p.Wo;
+    const int mt = (M + BM - 1) / BM;
+    const int nt = (p.cout + BN - 1) / BN;
+    int tile_id = blockIdx.x;
+    if (p.sched == 1) {
+        const int nwg = gridDim.x;
+        const int q8 = nwg >> 3, r8 = nwg & 7;
+        const int xcd = tile_id & 7;
+        tile_id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (tile_id >> 3);
+    }
+    int b, m0, n0;
+    if (p.sched == 1) {
+        const int ny = tile_id % nt;
+        const int rest = tile_id / nt;
+        n0 = ny * BN;
+        m0 = (rest % mt) * BM;
+        b = rest / mt;
+    } else {
+        m0 = (tile_id % mt) * BM;
+        const int rest = tile_id / mt;
+        n0 = (rest % nt) * BN;
+        b = rest / nt;
+    }
+
+    // ---- per-thread DMA slots: slot -> (row, physical quad); the lane fetches logical quad qp ^ swz(row) ----
+    int a_oy[A_IT], a_ox[A_IT];
+    unsigned a_qoff[A_IT];          // logical quad * 16 bytes
+    bool a_ok[A_IT], a_use[A_IT];
+#pragma unroll
+    for (int j = 0; j < A_IT; ++j) {
+        const int slot = tid + 256 * j;
+        const int row = slot / QPR;
+        const int qp = slot - row * QPR;
+        a_use[j] = slot < A_SLOTS;
+        a_qoff[j] = (unsigned)(qp ^ ((row / RPB) & (QPR - 1))) * 16u;
+        const int m = m0 + row;
+        a_ok[j] = a_use[j] && m < M;
+        const int oy = m / p.Wo;
+        a_oy[j] = oy * p.stride - p.padT;
+        a_ox[j] = (m - oy * p.Wo) * p.stride - p.padL;
+    }
+    unsigned b_off[B_IT];
+    bool b_use[B_IT];
+    const __amdgpu_buffer_rsrc_t b_rsrc = make_rsrc(p.w + (long)b * p.w_bs);
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+        const int slot = tid + 256 * it;
+        const int row = slot / QPR;
+        const int qp = slot - row * QPR;
+        b_use[it] = slot < B_SLOTS;
+        const bool ok = b_use[it] && (n0 + row) < p.w_rows;
+        b_off[it] = ok ? (unsigned)(n0 + row) * (unsigned)p.Ktot * 4u + (unsigned)(qp ^ ((row / RPB) & (QPR - 1))) * 16u : BUF_OOB;
+    }
+    // ---- fragment read addresses (bytes inside a ring slot), fixed for the whole loop ----
+    const int lr = lane & 31, lh = lane >> 5;
+    unsigned fa[TM][KCW / 8], fb[TN][KCW / 8];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int R = (wm * TM + i) * 32 + lr;
+#pragma unroll
+        for (int ks = 0; ks < KCW / 8; ++ks) {
+            const int q = wk * (KCW / 4) + ks * 2 + lh;
+            fa[i][ks] = (unsigned)(R * QPR + (q ^ ((R / RPB) & (QPR - 1)))) * 16u;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int R = (wn * TN + j) * 32 + lr;
+#pragma unroll
+        for (int ks = 0; ks < KCW / 8; ++ks) {
+            const int q = wk * (KCW / 4) + ks * 2 + lh;
+            fb[j][ks] = (unsigned)(BM * KS * 4) + (unsigned)(R * QPR + (q ^ ((R / RPB) & (QPR - 1)))) * 16u;
+        }
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nck = p.Ktot / KS;
+    int it_ky = 0, it_kx = 0, it_seg = 0, it_cs = 0, it_k = 0;
+    const int nseg = p.nseg, kw_n = p.KW;
+    const float* seg_base = p.in[0] + (long)b * p.seg_bs[0];
+    int seg_ld = p.seg_ld[0], seg_cn = p.seg_c[0];
+    const int g_hin = p.Hin, g_win = p.Win, g_padm = p.pad_mode;
+    int a_pix[A_IT];
+    auto tap_setup = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < A_IT; ++j) {
+            int iy = a_oy[j] + it_ky;
+            int ix = a_ox[j] + it_kx;
+            bool ok = a_ok[j];
+            if (g_padm == 1) {
+                iy = reflect_idx(iy, g_hin);
+                ix = reflect_idx(ix, g_win);
+            } else {
+                ok = ok && iy >= 0 && iy < g_hin && ix >= 0 && ix < g_win;
+            }
+            a_pix[j] = ok ? iy * g_win + ix : -1;
+        }
+    };
+    tap_setup();
+
+    // one stage: A_IT + B_IT wave-instructions per wave (a wave whose 64 slots lie past the tile issues nothing)
+    auto issue_stage = [&](int buf) __attribute__((always_inline)) {
+        float* base = smem + buf * STAGE;
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(seg_base);
+        const unsigned ld4 = (unsigned)seg_ld * 4u, so = (unsigned)it_cs * 4u;
+#pragma unroll
+        for (int j = 0; j < A_IT; ++j) {
+            if ((256 * j + 64 * wave) < A_SLOTS) {      // wave-uniform
+                const unsigned off = a_pix[j] < 0 ? BUF_OOB : (unsigned)a_pix[j] * ld4 + a_qoff[j];
+                dma16_to_lds(rs, base + (256 * j + 64 * wave) * 4, off, so);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            if ((256 * it + 64 * wave) < B_SLOTS)
+                dma16_to_lds(b_rsrc, base + BM * KS + (256 * it + 64 * wave) * 4, b_off[it], (unsigned)it_k * 4u);
+        }
+        // ---- advance the (wave-uniform) iterator ----
+        it_k += KS;
+        it_cs += KS;
+        if (it_cs >= seg_cn) {
+            it_cs = 0;
+            ++it_seg;
+            if (it_seg >= nseg) {
+                it_seg = 0;
+                ++it_kx;
+                if (it_kx >= kw_n) {
+                    it_kx = 0;
+                    ++it_ky;
+                }
+                tap_setup();
+            }
+            seg_base = sel3(p.in, it_seg) + (long)b * (it_seg == 0 ? p.seg_bs[0] : (it_seg == 1 ? p.seg_bs[1] : p.seg_bs[2]));
+            seg_ld = it_seg == 0 ? p.seg_ld[0] : (it_seg == 1 ? p.seg_ld[1] : p.seg_ld[2]);
+            seg_cn = it_seg == 0 ? p.seg_c[0] : (it_seg == 1 ? p.seg_c[1] : p.seg_c[2]);
+        }
+    };
+    // DMA wave-instructions THIS wave issues per stage (what the counted vmcnt leaves in flight)
+    int nl = 0;
+#pragma unroll
+    for (int j = 0; j < A_IT; ++j) nl += ((256 * j + 64 * wave) < A_SLOTS) ? 1 : 0;
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) nl += ((256 * it + 64 * wave) < B_SLOTS) ? 1 : 0;
+
+    issue_stage(0);
+    if (nck > 1) issue_stage(1);
+
+    int rbuf = 0, wbuf = 2;
+    for (int ck = 0; ck < nck; ++ck) {
+        // stage ck has landed once at most the loads of stage ck+1 are still in flight
+        if (ck + 1 < nck) wait_vmcnt_le(nl);
+        else wait_vmcnt0();
+        raw_barrier();
+        if (ck + 2 < nck) issue_stage(wbuf);
+        const char* sbase = reinterpret_cast<const char*>(smem + rbuf * STAGE);
+#pragma unroll
+        for (int ks = 0; ks < KCW / 8; ++ks) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(sbase + fa[i][ks]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(sbase + fb[j][ks]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        }
+        rbuf = rbuf == NBUF - 1 ? 0 : rbuf + 1;
+        wbuf = wbuf == NBUF - 1 ? 0 : wbuf + 1;
+    }
+    wait_lgkm0();
+    raw_barrier();          // every wave is done reading the ring before it is reused below
+
+    if (WK > 1) {
+        float* red = smem;
+        if (wk > 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        red[((((wk - 1) * WMN + wmn) * TM + i) * TN + j) * 1024 + r * 64 + lane] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (wk > 0) return;
+#pragma unroll
+        for (int k = 1; k < WK; ++k)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[i][j][r] += red[((((k - 1) * WMN + wmn) * TM + i) * TN + j) * 1024 + r * 64 + lane];
+    }
+
+    float* sW = smem + RED + wmn * (32 * EPI_S);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                sW[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_S + lr] = acc[i][j][r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int nb = n0 + (wn * TN + j) * 32 + (lane & 7) * 4;
+            const int mb = m0 + (wm * TM + i) * 32 + (lane >> 3);
+#pragma unroll 1
+            for (int it = 0; it < 4; ++it) {
+                const int m = mb + it * 8;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(sW + ((lane >> 3) + it * 8) * EPI_S + (lane & 7) * 4);
+                if (m < M && nb < p.cout) epilogue4(p, b, m, nb, v);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int WK, int KCW>
+static hipError_t launch_dma(const ConvParams& p, int batch, hipStream_t s) {
+    if (p.a_mode != A_NHWC || p.prec != 0 || !stage_ok(p, KCW * WK)) return hipErrorInvalidValue;
+    const int M = p.Ho * p.Wo;
+    dim3 grid(((M + BM - 1) / BM) * ((p.cout + BN - 1) / BN) * batch);
+    hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, WK, KCW>), grid, dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
 // tile ids: 1 = 128x128, 2 = 128x64, 3 = 128x96, 4 = 64x64, 5 = 64x128, 6 = 128x32
 // ---------------------------------------------------------------------------
 // Convolutions with 1-2 output channels (FlowHead.conv2 256->2, final_conv 64->1): on the matrix
@@ -770,6 +1073,14 @@ const char* conv_tile_name(int tile) {
         case 12: return "conv_igemm_kernel<64,64,2,2,1,kcw32>";
         case 13: return "conv_igemm_kernel<128,128,2,2,1,kcw32>";
         case 14: return "conv_igemm_kernel<128,64,2,2,1,kcw32>";
+        case 20: return "conv_dma_kernel<32,64,1,2,2,16>";
+        case 21: return "conv_dma_kernel<32,64,1,2,2,32>";
+        case 22: return "conv_dma_kernel<32,32,1,1,4,16>";
+        case 23: return "conv_dma_kernel<64,64,2,2,1,16>";
+        case 24: return "conv_dma_kernel<64,64,2,2,1,32>";
+        case 25: return "conv_dma_kernel<128,128,2,2,1,16>";
+        case 26: return "conv_dma_kernel<128,64,2,2,1,16>";
+        case 27: return "conv_dma_kernel<128,64,2,2,1,32>";
         default: return "?";
     }
 }
@@ -778,6 +1089,15 @@ static int default_sched() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("CF_SCHED");
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
+
+static int default_dma() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("CF_DMA");
         v = e ? atoi(e) : 1;
     }
     return v;
@@ -853,6 +1173,14 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
         // segments allow them (tools/conv_bench.py, MI355X)
         if (tile == 9 && stage_ok(p, 64)) tile = 10;
         else if (tile == 4 && stage_ok(p, 32)) tile = 12;
+        // plain NHWC reads in fp32 go through the LDS-DMA kernel (3-15 % faster per layer, same arithmetic order)
+        if (p.a_mode == A_NHWC && p.prec == 0 && default_dma()) {
+            if (tile == 9 || tile == 10) tile = 20;
+            else if (tile == 8 && stage_ok(p, 64)) tile = 22;
+            else if (tile == 4 || tile == 12) tile = 23;
+            else if (tile == 2) tile = 26;
+            else if (tile == 1) tile = (p.cout >= 256 && p.cout % 64 == 0) ? 26 : 23;   // in-model sweep (tools/tile_sweep.sh)
+        }
     }
     if (tile_used) *tile_used = tile;
     if (p.prec != 0 && p.prec != 1 && p.prec != 3) return hipErrorInvalidValue;
@@ -878,6 +1206,14 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
         case 12: return stage_ok(p, 32) ? launch_t<64, 64, 2, 2, 1, 32>(p, batch, s) : hipErrorInvalidValue;
         case 13: return stage_ok(p, 32) ? launch_t<128, 128, 2, 2, 1, 32>(p, batch, s) : hipErrorInvalidValue;
         case 14: return stage_ok(p, 32) ? launch_t<128, 64, 2, 2, 1, 32>(p, batch, s) : hipErrorInvalidValue;
+        case 20: return launch_dma<32, 64, 1, 2, 2, 16>(p, batch, s);
+        case 21: return launch_dma<32, 64, 1, 2, 2, 32>(p, batch, s);
+        case 22: return launch_dma<32, 32, 1, 1, 4, 16>(p, batch, s);
+        case 23: return launch_dma<64, 64, 2, 2, 1, 16>(p, batch, s);
+        case 24: return launch_dma<64, 64, 2, 2, 1, 32>(p, batch, s);
+        case 25: return launch_dma<128, 128, 2, 2, 1, 16>(p, batch, s);
+        case 26: return launch_dma<128, 64, 2, 2, 1, 16>(p, batch, s);
+        case 27: return launch_dma<128, 64, 2, 2, 1, 32>(p, batch, s);
         default: return hipErrorInvalidValue;
     }
 }

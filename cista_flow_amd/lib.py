@@ -156,12 +156,12 @@ class Handle:
 
     def profile_read(self):
         """-> list of dicts per conv tile kind: name, ms, flops, count (index 0 = all conv launches)."""
-        n = 16
+        n = 32
         ms, fl, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_longlong * n)()
         self.check(self.lib.cf_profile_read(self.h, ms, fl, cnt, n), "cf_profile_read")
         out = []
         for t in range(n):
-            name = "conv_igemm_kernel<*>" if t == 0 else self.lib.cf_conv_tile_name(t).decode()
+            name = "conv_*_kernel<*>" if t == 0 else self.lib.cf_conv_tile_name(t).decode()
             out.append(dict(name=name, ms=ms[t], flops=fl[t], count=int(cnt[t])))
         return out
 

@@ -90,6 +90,19 @@ CONV_CASES = [
     (96, 96, 3, 3, 1, 1, 1, 0, 12),
     (192, 256, 3, 3, 1, 1, 1, 1, 13),
     (128, 64, 3, 3, 2, 1, 1, 1, 14),
+    (128, 256, 3, 3, 1, 1, 1, 0, 20),  # LDS-DMA staged variants (3-deep ring, swizzled rows)
+    (96, 96, 3, 3, 2, 1, 1, 0, 20),
+    (384, 126, 5, 1, 1, 2, 0, 0, 20),
+    (128, 256, 3, 3, 1, 1, 1, 1, 21),
+    (256, 128, 1, 5, 1, 0, 2, 0, 22),
+    (64, 96, 3, 3, 1, 1, 1, 1, 22),
+    (96, 96, 3, 3, 1, 1, 1, 0, 23),
+    (16, 96, 3, 3, 1, 1, 1, 0, 23),
+    (64, 128, 3, 3, 2, 1, 1, 1, 24),
+    (192, 256, 3, 3, 1, 1, 1, 1, 25),
+    (336, 256, 1, 1, 1, 0, 0, 0, 25),
+    (128, 64, 3, 3, 1, 1, 1, 1, 26),
+    (64, 128, 3, 3, 1, 1, 1, 0, 27),
 ]
 
 

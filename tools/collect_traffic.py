@@ -26,6 +26,8 @@ def per_kernel(d, counter):
             if m:   # fold the A-mode / precision instantiations of one tile shape together (bench.py's names)
                 g = m.groups()
                 n = "%s<%s,%s,%s,%s,%s%s>" % (g[0], g[1], g[2], g[3], g[4], g[5], ",kcw32" if g[6] == "32" else "")
+            elif re.match(r"void cf::conv_dma_kernel<", n):
+                n = re.sub(r"^void cf::", "", n).split("(")[0].replace(" ", "")
             else:
                 n = re.sub(r"^void ", "", n).split("(")[0].replace("cf::", "")
                 n = re.sub(r"<.*>", "", n) if n.startswith("conv_smalln") else n

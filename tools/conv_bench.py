@@ -28,6 +28,9 @@ SHAPES = [
     ("cista.D   128->64  3x3 @90x120", 8, 128, 90, 120, 64, 3, 3, 1, 1, 1, 1),
     ("cista.P    64->128 3x3 @90x120", 8, 64, 90, 120, 128, 3, 3, 1, 1, 1, 1),
     ("gates     192->256 3x3 @90x120", 8, 192, 90, 120, 256, 3, 3, 1, 1, 1, 1),
+    ("out_gates 256->128 3x3 @90x120", 8, 256, 90, 120, 128, 3, 3, 1, 1, 1, 1),
+    ("Gates     128->256 3x3 @90x120", 8, 128, 90, 120, 256, 3, 3, 1, 1, 1, 1),
+    ("W0         64->64  3x3/2 @180x240", 8, 64, 180, 240, 64, 3, 3, 2, 1, 1, 1),
 ]
 
 
@@ -53,7 +56,10 @@ def run(shape, tile, iters=20):
 
 def main():
     tiles = [int(t) for t in os.environ.get("TILES", "0,1,2,4,8,9,10,11,12,13,14").split(",")]
+    only = os.environ.get("SHAPES")
     for sh in SHAPES:
+        if only and not any(o in sh[0] for o in only.split(",")):
+            continue
         res = []
         for t in tiles:
             r = run(sh, t)
