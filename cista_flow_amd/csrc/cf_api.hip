@@ -19,6 +19,7 @@
 
 namespace cf {
 long inorm_partial_doubles(int B, int HW, int C);
+long inorm_patch_doubles(int B, int HW, int C);
 }
 
 using namespace cf;
@@ -113,6 +114,24 @@ struct cf_handle {
     std::string prof_report;
     bool prof = false;
     bool serial = false;   // measurement mode: no side-stream concurrency
+    // CF_PHASES=1 (tuning aid): HIP events on the caller's stream at the phase boundaries of cf_step, averaged
+    // and printed to stderr by cf_destroy
+    bool phases = false;
+    hipEvent_t ph_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ph_pending = false;
+    double ph_ms[3] = {0, 0, 0};
+    long ph_n = 0;
+    void phase_mark(int i, hipStream_t st) { if (phases) (void)hipEventRecord(ph_ev[i], st); }
+    void phase_collect() {
+        if (!phases || !ph_pending) return;
+        ph_pending = false;
+        if (hipEventSynchronize(ph_ev[3]) != hipSuccess) return;
+        for (int i = 0; i < 3; ++i) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, ph_ev[i], ph_ev[i + 1]) == hipSuccess) ph_ms[i] += t;
+        }
+        ++ph_n;
+    }
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> prof_pool;
     hipEvent_t prof_event() {
@@ -208,7 +227,7 @@ static void setup_buffers(cf_handle* H_) {
             s.enc[e].D = a.f(B * P1 * 64);
             s.enc[e].stats = a.f(B * 256 * 2);
             s.enc[e].stats2 = a.f(B * 256 * 2);
-            s.enc[e].partial = reinterpret_cast<double*>(a.raw(sizeof(double) * (size_t)inorm_partial_doubles(s.B, (int)P1, 128)));
+            s.enc[e].partial = reinterpret_cast<double*>(a.raw(sizeof(double) * (size_t)inorm_patch_doubles(s.B, (int)P1, 128)));
         }
         s.fmap1 = a.f(B * N * 256);
         s.emap = a.f(B * N * 256);
@@ -630,6 +649,10 @@ extern "C" int cf_create(cf_handle** out, const cf_config* cfg) {
         return CF_ERR_HIP;
     }
     bool ok = true;
+    if (const char* e = getenv("CF_PHASES")) {
+        h->phases = atoi(e) != 0;
+        for (int i = 0; h->phases && i < 4; ++i) ok = ok && hipEventCreate(&h->ph_ev[i]) == hipSuccess;
+    }
     for (int i = 0; i < 2; ++i) {
         ok = ok && hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming) == hipSuccess;
@@ -659,6 +682,13 @@ extern "C" void cf_destroy(cf_handle* h) {
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->phases) {
+        h->phase_collect();
+        if (h->ph_n > 0)
+            fprintf(stderr, "[cistaflow] phases over %ld steps (ms): flow encoders+corr %.3f | update iterations %.3f | warp+CISTA %.3f\n",
+                    h->ph_n, h->ph_ms[0] / h->ph_n, h->ph_ms[1] / h->ph_n, h->ph_ms[2] / h->ph_n);
+        for (int i = 0; i < 4; ++i) if (h->ph_ev[i]) (void)hipEventDestroy(h->ph_ev[i]);
+    }
     for (auto& r : h->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : h->prof_pool) (void)hipEventDestroy(e);
     delete h;
@@ -835,9 +865,10 @@ static int encoder_forward(cf_handle* h, const std::string& pre, bool bn, const 
     {
         ConvParams p = gather_conv(K("conv1"), in, Cin, h->H, h->W, h->padH, h->padW, scale, shift, 0, Hc, Wc, 2, 3, 3, 0,
                                    bn ? A : Bf, 64, (long)Hc * Wc * 64, bn ? EPI_RELU : EPI_NONE);
+        if (!bn) p.st_partial = sc.partial;      // InstanceNorm statistics ride on the conv epilogue
         CF_HIP(h, run_conv(h, p, B, st));
         if (!bn) {
-            CF_HIP(h, launch_inorm_stats(Bf, 64, (long)Hc * Wc * 64, B, Hc * Wc, 64, eps, sc.partial, sc.stats, st));
+            CF_HIP(h, launch_inorm_final(sc.partial, (Hc * Wc + 31) / 32, B, Hc * Wc, 64, eps, sc.stats, st));
             CF_HIP(h, launch_inorm_apply(Bf, 64, (long)Hc * Wc * 64, sc.stats, nullptr, 0, 0, nullptr, A, 64,
                                          (long)Hc * Wc * 64, B, Hc * Wc, 64, st));
         }
@@ -870,20 +901,23 @@ static int encoder_forward(cf_handle* h, const std::string& pre, bool bn, const 
                 std::swap(A, Df);
             } else {
                 ConvParams c1 = nhwc_conv(K(b + ".conv1"), {{A, Cx, Cx, ibs}}, Hc, Wc, Ho, Wo, stride, 1, 1, 0, Bf, Cd, obs, EPI_NONE);
+                c1.st_partial = sc.partial;
                 CF_HIP(h, run_conv(h, c1, B, st));
-                CF_HIP(h, launch_inorm_stats(Bf, Cd, obs, B, Ho * Wo, Cd, eps, sc.partial, sc.stats, st));
+                CF_HIP(h, launch_inorm_final(sc.partial, (Ho * Wo + 31) / 32, B, Ho * Wo, Cd, eps, sc.stats, st));
                 CF_HIP(h, launch_inorm_apply(Bf, Cd, obs, sc.stats, nullptr, 0, 0, nullptr, Cf, Cd, obs, B, Ho * Wo, Cd, st));
                 ConvParams c2 = nhwc_conv(K(b + ".conv2"), {{Cf, Cd, Cd, obs}}, Ho, Wo, Ho, Wo, 1, 1, 1, 0, Bf, Cd, obs, EPI_NONE);
+                c2.st_partial = sc.partial;
                 CF_HIP(h, run_conv(h, c2, B, st));
-                CF_HIP(h, launch_inorm_stats(Bf, Cd, obs, B, Ho * Wo, Cd, eps, sc.partial, sc.stats, st));
+                CF_HIP(h, launch_inorm_final(sc.partial, (Ho * Wo + 31) / 32, B, Ho * Wo, Cd, eps, sc.stats, st));
                 const float* res = A;
                 int res_ld = Cx;
                 long res_bs = ibs;
                 const float* res_stats = nullptr;
                 if (stride != 1) {
                     ConvParams ds = nhwc_conv(K(b + ".downsample.0"), {{A, Cx, Cx, ibs}}, Hc, Wc, Ho, Wo, stride, 0, 0, 0, Cf, Cd, obs, EPI_NONE);
+                    ds.st_partial = sc.partial;
                     CF_HIP(h, run_conv(h, ds, B, st));
-                    CF_HIP(h, launch_inorm_stats(Cf, Cd, obs, B, Ho * Wo, Cd, eps, sc.partial, sc.stats2, st));
+                    CF_HIP(h, launch_inorm_final(sc.partial, (Ho * Wo + 31) / 32, B, Ho * Wo, Cd, eps, sc.stats2, st));
                     res = Cf; res_ld = Cd; res_bs = obs; res_stats = sc.stats2;
                 }
                 CF_HIP(h, launch_inorm_apply(Bf, Cd, obs, sc.stats, res, res_ld, res_bs, res_stats, Df, Cd, obs, B, Ho * Wo, Cd, st));
@@ -984,6 +1018,7 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
         for (int l = 1; l < 4; ++l)
             CF_HIP(h, launch_corr_pool(h->corr[l - 1], h->corr[l], (long)B * N, h->clh[l - 1], h->clw[l - 1], st));
     }
+    h->phase_mark(1, st);
     CF_HIP(h, launch_coords_init(h->coords1, flow_init, B, h8, w8, st));
     if (flag) CF_HIP(h, hipMemsetAsync(flag, 0, sizeof(int), st));
     const int iters = h->cfg.iters;
@@ -1185,12 +1220,15 @@ extern "C" int cf_step(cf_handle* h, const float* in0, const float* in1, const f
     hipStream_t st = static_cast<hipStream_t>(stream);
     CF_HIP(h, hipSetDevice(h->cfg.device));
     int rc;
+    h->phase_collect();
+    h->phase_mark(0, st);
     // flow estimation from E_0^1 and the previous reconstruction (e2v_model.py:170-174)
     if (h->cfg.mode == CF_MODE_IDNET) {
         if ((rc = idnet_forward(h, in0, flow_init, flow_final, flow_low, flow_preds, h->flag, st))) return rc;
     } else if ((rc = eiflow_forward(h, in0, in1, flow_init, flow_final, flow_low, flow_preds, h->flag, st))) {
         return rc;
     }
+    h->phase_mark(2, st);
     const float* flow = flow_final;
     if (gt_flow) {   // e2v_model.py:181-182
         flow = gt_flow;
@@ -1209,7 +1247,10 @@ extern "C" int cf_step(cf_handle* h, const float* in0, const float* in1, const f
     }
     // CISTA consumes the current voxel grid: in0 for eiflow, in1 (= image2) for eraft (e2v_model.py:194,246)
     const float* ev_now = h->cfg.mode == CF_MODE_ERAFT ? in1 : in0;
-    return cista_forward(h, ev_now, h->warpedI, c_prev, zin, h_prev, cc_prev, I_out, c_out, z_out, h_out, cc_out, st);
+    rc = cista_forward(h, ev_now, h->warpedI, c_prev, zin, h_prev, cc_prev, I_out, c_out, z_out, h_out, cc_out, st);
+    h->phase_mark(3, st);
+    h->ph_pending = h->phases && rc == CF_OK;
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1224,7 +1265,8 @@ struct TmpBuf {
 
 static int op_conv2d_impl(const float* in, int B, int Cin, int H, int W, const float* weight, const float* bias, int Cout,
                           int KH, int KW, int stride, int padT, int padL, int pad_mode, int a_mode, int epi, int tile,
-                          float* out, void* stream, int iters, float* ms_out, int prec) {
+                          float* out, void* stream, int iters, float* ms_out, int prec, float* stats_out = nullptr,
+                          float eps = 0.f) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (!in || !weight || !out || B < 1 || Cin < 1 || Cout < 1 || stride < 1) return CF_ERR_ARG;
     const bool gather = a_mode == A_GATHER;
@@ -1265,8 +1307,15 @@ static int op_conv2d_impl(const float* in, int B, int Cin, int H, int W, const f
         p.w16 = w16.p;
         p.prec = prec;
     }
+    TmpBuf part;
+    if (stats_out) {   // fused InstanceNorm statistics
+        if (hipMalloc(&part.p, sizeof(double) * (size_t)inorm_patch_doubles(B, Ho * Wo, Cout)) != hipSuccess) return CF_ERR_HIP;
+        p.st_partial = static_cast<double*>(part.p);
+    }
     hipError_t e = launch_conv(p, B, st, tile);
     if (e != hipSuccess) return e == hipErrorInvalidValue ? CF_ERR_ARG : CF_ERR_HIP;
+    if (stats_out && launch_inorm_final(p.st_partial, (Ho * Wo + 31) / 32, B, Ho * Wo, Cout, eps, stats_out, st) != hipSuccess)
+        return CF_ERR_HIP;
     if (iters > 0 && ms_out) {   // timing loop for tools/conv_bench.py
         hipEvent_t a, b;
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return CF_ERR_HIP;
@@ -1289,6 +1338,15 @@ extern "C" int cf_op_conv2d(const float* in, int B, int Cin, int H, int W, const
                             float* out, void* stream) {
     return op_conv2d_impl(in, B, Cin, H, W, weight, bias, Cout, KH, KW, stride, padT, padL, pad_mode, a_mode, epi, tile, out,
                           stream, 0, nullptr, 0);
+}
+
+// conv (EPI_NONE) + InstanceNorm statistics taken in its epilogue: stats_out [B][Cout][2] = {mean, 1/sqrt(var + eps)}
+extern "C" int cf_op_conv2d_inorm_stats(const float* in, int B, int Cin, int H, int W, const float* weight, const float* bias,
+                                        int Cout, int KH, int KW, int stride, int padT, int padL, int pad_mode, int a_mode,
+                                        int tile, float* out, float* stats_out, float eps, void* stream) {
+    if (!stats_out) return CF_ERR_ARG;
+    return op_conv2d_impl(in, B, Cin, H, W, weight, bias, Cout, KH, KW, stride, padT, padL, pad_mode, a_mode, EPI_NONE, tile, out,
+                          stream, 0, nullptr, 0, stats_out, eps);
 }
 
 // same op launched `iters` times between two HIP events; *ms_out = average launch duration (tuning tool)

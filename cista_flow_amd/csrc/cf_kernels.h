@@ -86,6 +86,10 @@ struct ConvParams {
     int  prec;          // 0 fp32 MFMA, 3 f16x3 split MFMA, 1 plain f16 MFMA (w must point at the matching copy)
     int  b_f32;         // f16 modes: B operand is fp32 activations (correlation GEMM), split while staging
     int  sched;         // workgroup->tile map: -1 default (env CF_SCHED, else 1), 0 m-fastest, 1 XCD-aware
+    // fused InstanceNorm statistics (EPI_NONE only): every 32-pixel x cout patch of the output adds its fp64
+    // {sum, sum of squares} of v = acc + bias to st_partial[b][ceil(M/32)][cout][2]; launch_inorm_final folds them
+    double* st_partial;
+    int  epi_vec;       // set by launch_conv: out / out2 / aux / addend rows are 16-byte aligned (dwordx4 tail)
 };
 
 // tile: 0 auto, else explicit (see conv_igemm.hip); tile_used (nullable) returns the choice
@@ -125,6 +129,10 @@ hipError_t launch_any_nonzero(const float* x, long n, int* flag, hipStream_t s);
 
 // InstanceNorm2d(affine=False, eps): two-stage statistics + apply.
 //   stats[b][c] = {mean, rstd}
+// fold partial sums [B][nchunk][C][2] (launch_inorm_stats' own, or ConvParams::st_partial with nchunk = ceil(HW/32))
+// into stats [B][C][2] = {mean, 1/sqrt(var + eps)} (biased variance)
+hipError_t launch_inorm_final(const double* partial, int nchunk, int B, int HW, int C, float eps, float* stats,
+                              hipStream_t s);
 hipError_t launch_inorm_stats(const float* x, int ld, long bs, int B, int HW, int C, float eps,
                               double* partial, float* stats, hipStream_t s);
 // out = relu(norm(x))                                   (res == nullptr)

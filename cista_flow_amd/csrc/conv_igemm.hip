@@ -220,6 +220,202 @@ __device__ __forceinline__ void epilogue4(const ConvParams& p, int b, int m, int
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Fast tail of a 32x32 patch whose 32 columns are all real couts and whose aux / out rows are 16-byte aligned
+// (p.epi_vec, checked on the host).  The wave's sub-tile sits in its LDS patch (row = pixel, stride EPI_S); a
+// lane owns channel quad (lane & 7) of pixel rows (lane >> 3) + 8 it.  All global accesses are raw buffer
+// dwordx4 operations on a wave-uniform descriptor (tensor base of image b) with a 32-bit per-lane offset, so rows
+// past M are masked by the out-of-range offset (loads return 0, stores are dropped) instead of by branches, and
+// the loads of EPI_BATCH quads are in flight together -- the earlier tail (one dependent scalar load -> store
+// chain per quad) cost ~26k cycles per 128x64 tile.
+// ---------------------------------------------------------------------------------------------------------
+#ifndef EPI_BATCH
+#define EPI_BATCH 1
+#endif
+#ifndef WPE2
+#define WPE2 4
+#endif
+struct EpiAux {
+    f32x4 a0, a1, a2, a3;     // aux0 | aux1 | aux2 or addend | second half of aux0 (LSTC forget gate)
+};
+
+__device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
+}
+
+__device__ __forceinline__ void patch_tail_fast(const ConvParams& p, const float* sW, int b, int mrow0, int nbase, int lane,
+                                                int M) {
+    const int n = nbase + (lane & 7) * 4;
+    const int mb = mrow0 + (lane >> 3);
+    const int epi = p.epi;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, lam4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bias4 = buf_load4(make_rsrc(p.bias), 4u * (unsigned)n, 0);
+    if (epi == EPI_ADD_AUX_SHRINK) lam4 = buf_load4(make_rsrc(p.lam), 4u * (unsigned)n, 0);
+    const bool has_add = p.addend != nullptr;
+    // descriptors of absent tensors are built from null + offset and never used (a pointer select here makes
+    // hipcc copy the whole by-value ConvParams to scratch)
+    const __amdgpu_buffer_rsrc_t r_out = make_rsrc(p.out + (long)b * p.out_bs);
+    const __amdgpu_buffer_rsrc_t r_out2 = make_rsrc(p.out2 + (long)b * p.out2_bs);
+    const __amdgpu_buffer_rsrc_t r_a0 = make_rsrc(p.aux0 + (long)b * p.aux0_bs);
+    const __amdgpu_buffer_rsrc_t r_a1 = make_rsrc(p.aux1 + (long)b * p.aux1_bs);
+    const __amdgpu_buffer_rsrc_t r_a2 = make_rsrc(has_add ? p.addend + (long)b * p.addend_bs : p.aux2 + (long)b * p.aux2_bs);
+    const unsigned ld_a2 = 4u * (unsigned)(has_add ? p.addend_ld : p.aux2_ld);
+    const unsigned n4 = 4u * (unsigned)n;
+    const bool zr_hi = epi == EPI_GRU_ZR && n >= p.split;          // r half of the z|r conv (per quad)
+    const bool sp_hi = epi == EPI_TANH_RELU_SPLIT && n >= p.split;
+    const unsigned n4_hi = 4u * (unsigned)(n - p.split);
+#pragma unroll
+    for (int h = 0; h < 4; h += EPI_BATCH) {
+        EpiAux x[EPI_BATCH];
+#pragma unroll
+        for (int it = 0; it < EPI_BATCH; ++it) {
+            const int m = mb + (h + it) * 8;
+            const bool ok = m < M;
+            const unsigned um = (unsigned)m;
+            if (has_add || epi == EPI_LSTC) x[it].a2 = buf_load4(r_a2, ok ? um * ld_a2 + n4 : BUF_OOB, 0);
+            switch (epi) {
+                case EPI_SUB_FROM_AUX:
+                case EPI_ADD_AUX_SHRINK:
+                case EPI_RELU_ADD_AUX:
+                case EPI_RELU_ADD_AUX_RELU:
+                    x[it].a0 = buf_load4(r_a0, ok ? um * (4u * (unsigned)p.aux0_ld) + n4 : BUF_OOB, 0);
+                    break;
+                case EPI_LSTC:
+                    x[it].a0 = buf_load4(r_a0, ok ? um * (4u * (unsigned)p.aux0_ld) + n4 : BUF_OOB, 0);
+                    x[it].a3 = buf_load4(r_a0, ok ? um * (4u * (unsigned)p.aux0_ld) + n4 + 4u * (unsigned)p.split : BUF_OOB, 0);
+                    x[it].a1 = buf_load4(r_a1, ok ? um * (4u * (unsigned)p.aux1_ld) + n4 : BUF_OOB, 0);
+                    break;
+                case EPI_GRU_ZR:
+                    x[it].a0 = buf_load4(r_a0, (ok && zr_hi) ? um * (4u * (unsigned)p.aux0_ld) + n4_hi : BUF_OOB, 0);
+                    break;
+                case EPI_GRU_Q:
+                    x[it].a0 = buf_load4(r_a0, ok ? um * (4u * (unsigned)p.aux0_ld) + n4 : BUF_OOB, 0);
+                    x[it].a1 = buf_load4(r_a1, ok ? um * (4u * (unsigned)p.aux1_ld) + n4 : BUF_OOB, 0);
+                    break;
+                default: break;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < EPI_BATCH; ++it) {
+            const int m = mb + (h + it) * 8;
+            const bool ok = m < M;
+            const unsigned um = (unsigned)m;
+            const f32x4 acc = *reinterpret_cast<const f32x4*>(sW + ((lane >> 3) + (h + it) * 8) * EPI_S + (lane & 7) * 4);
+            const EpiAux& a = x[it];
+            f32x4 v, o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[e] + bias4[e];
+            if (has_add) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += a.a2[e];
+            }
+            o = v;
+            bool to_out = true;
+            switch (epi) {
+                case EPI_RELU:
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = fmaxf(v[e], 0.f);
+                    break;
+                case EPI_SIGMOID:
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = sigmoidf_(v[e]);
+                    break;
+                case EPI_TANH:
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = tanhf(v[e]);
+                    break;
+                case EPI_SUB_FROM_AUX:
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = a.a0[e] - v[e];
+                    break;
+                case EPI_ADD_AUX_SHRINK:
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = v[e] + a.a0[e];
+                        o[e] = fmaxf(t - lam4[e], 0.f) - fmaxf(-t - lam4[e], 0.f);
+                    }
+                    break;
+                case EPI_RELU_ADD_AUX:
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = fmaxf(v[e], 0.f) + a.a0[e];
+                    break;
+                case EPI_RELU_ADD_AUX_RELU:
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = fmaxf(a.a0[e] + fmaxf(v[e], 0.f), 0.f);
+                    break;
+                case EPI_LSTC: {
+                    // aux0 = sigmoid gates [px][2*split] (i | f), aux1 = z0, aux2 = c_prev; out = z, out2 = c
+                    f32x4 c;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        c[e] = a.a3[e] * a.a2[e] + a.a0[e] * a.a1[e];
+                        o[e] = sigmoidf_(v[e]) * tanhf(c[e]);
+                    }
+                    buf_store4(r_out2, ok ? um * (4u * (unsigned)p.out2_ld) + n4 : BUF_OOB, c);
+                } break;
+                case EPI_GRU_ZR:
+                    if (zr_hi) {
+                        to_out = false;
+                        f32x4 r;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) r[e] = sigmoidf_(v[e]) * a.a0[e];
+                        buf_store4(r_out2, ok ? um * (4u * (unsigned)p.out2_ld) + n4_hi : BUF_OOB, r);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = sigmoidf_(v[e]);
+                    }
+                    break;
+                case EPI_GRU_Q:
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (1.f - a.a0[e]) * a.a1[e] + a.a0[e] * tanhf(v[e]);
+                    break;
+                case EPI_TANH_RELU_SPLIT:
+                    if (sp_hi) {
+                        to_out = false;
+                        f32x4 r;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) r[e] = fmaxf(v[e], 0.f);
+                        buf_store4(r_out2, ok ? um * (4u * (unsigned)p.out2_ld) + n4_hi : BUF_OOB, r);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = tanhf(v[e]);
+                    }
+                    break;
+                case EPI_SCALE:
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = acc[e] * p.scale;
+                    break;
+                case EPI_BIAS_SCALE:
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = v[e] * p.scale;
+                    break;
+                case EPI_LSTM_ACT:
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (n < p.split) ? sigmoidf_(v[e]) : tanhf(v[e]);
+                    break;
+                default: break;
+            }
+            buf_store4(r_out, (ok && to_out) ? um * (4u * (unsigned)p.out_ld) + n4 : BUF_OOB, o);
+        }
+    }
+}
+
+// generic tail: any alignment, partial quads, strided outputs (out_cs != 1), EPI_ADD_AUX
+__device__ __forceinline__ void patch_tail(const ConvParams& p, const float* sW, int b, int mrow0, int nbase, int lane, int M) {
+    if (p.epi_vec && nbase + 32 <= p.cout) {      // wave-uniform
+        patch_tail_fast(p, sW, b, mrow0, nbase, lane, M);
+        return;
+    }
+    const int nb = nbase + (lane & 7) * 4;
+    const int mb = mrow0 + (lane >> 3);
+#pragma unroll 1
+    for (int it = 0; it < 4; ++it) {
+        const int m = mb + it * 8;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sW + ((lane >> 3) + it * 8) * EPI_S + (lane & 7) * 4);
+        if (m < M && nb < p.cout) epilogue4(p, b, m, nb, v);
+    }
+}
+
 // WK > 1: intra-workgroup split-K.  The 4 waves are arranged WAVES_M x WAVES_N x WK; one stage holds
 // 16*WK k-columns and wave (.., wk) consumes columns [16*wk, 16*wk+16).  The partial accumulators are summed
 // through LDS before the epilogue.  This keeps 4 waves busy on 32x32 / 32x64 output tiles, which is what the
@@ -232,6 +428,36 @@ __device__ __forceinline__ void epilogue4(const ConvParams& p, int b, int m, int
 // 16 fp32, so tile geometry, strides and the pre-split weight copies (same format in HBM) are shared.
 // KCW: k-columns one wave consumes per stage (16 or 32).  32 doubles the MFMA work between two barriers, which
 // is what the small tiles need (their fixed per-stage cost -- iterator, waits, barrier -- rivals 8 MFMAs).
+// Fused InstanceNorm statistics: the wave's 32-pixel x 32-channel patch (raw accumulators, row stride EPI_S)
+// is summed down its columns in fp64 -- lane = channel, the two half-waves take 16 rows each -- over
+// v = acc + bias exactly as stored, and written to st_partial[b][patch][cout][2] (every element once).
+__device__ __forceinline__ void patch_stats(const ConvParams& p, const float* sW, int b, int mrow0, int nbase, int lane,
+                                            int M) {
+    const int c = lane & 31, half = lane >> 5;
+    const int n = nbase + c;
+    const int nvalid = M - mrow0;          // rows of this patch inside the image (<= 0: patch is all padding)
+    const float bv = (p.bias && n < p.cout) ? p.bias[n] : 0.f;
+    double s = 0.0, ss = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = half * 16 + r;
+        if (row < nvalid) {
+            const double d = (double)(sW[row * EPI_S + c] + bv);
+            s += d;
+            ss += d * d;
+        }
+    }
+    s += __shfl_xor(s, 32);
+    ss += __shfl_xor(ss, 32);
+    if (half == 0 && nvalid > 0 && n < p.cout) {
+        const long npatch = (M + 31) >> 5;
+        double2 o;
+        o.x = s;
+        o.y = ss;
+        *reinterpret_cast<double2*>(p.st_partial + (((long)b * npatch + (mrow0 >> 5)) * p.cout + n) * 2) = o;
+    }
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int WK, int AMODE, int PREC, int KCW = 16>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     static_assert(KCW == 16 || KCW == 32, "KCW");
@@ -615,28 +841,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     // 32x32 sub-tile goes through a per-wave LDS patch so that a lane ends up with 4 consecutive
     // couts of one pixel: aux reads and the store are then 16-byte accesses on 128-byte rows.
     float* sW = smem + RED + wmn * (32 * EPI_S);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                sW[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_S + lr] = acc[i][j][r];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int nb = n0 + (wn * TN + j) * 32 + (lane & 7) * 4;
-            const int mb = m0 + (wm * TM + i) * 32 + (lane >> 3);
+    // One run-time loop over the wave's TM x TN sub-tiles: the (large) tail code exists once, and the compiler
+    // cannot hoist every sub-tile's loads / address arithmetic to the top (which cost 60-130 VGPRs when the loop
+    // was unrolled).  Only the copy of the accumulators into the patch is selected per sub-tile.
 #pragma unroll 1
-            for (int it = 0; it < 4; ++it) {
-                const int m = mb + it * 8;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(sW + ((lane >> 3) + it * 8) * EPI_S + (lane & 7) * 4);
-                if (m < M && nb < p.cout) epilogue4(p, b, m, nb, v);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
+    for (int pi = 0; pi < TM * TN; ++pi) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                if (pi == i * TN + j) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        sW[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_S + lr] = acc[i][j][r];
+                }
+        const int pi_i = pi / TN, pi_j = pi - pi_i * TN;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        patch_tail(p, sW, b, m0 + (wm * TM + pi_i) * 32, n0 + (wn * TN + pi_j) * 32, lane, M);
+        if (p.st_partial) patch_stats(p, sW, b, m0 + (wm * TM + pi_i) * 32, n0 + (wn * TN + pi_j) * 32, lane, M);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
@@ -706,8 +933,25 @@ __device__ __forceinline__ void raw_barrier() {
     asm volatile("" ::: "memory");
 }
 
+// Second launch bound = waves per SIMD the register allocation must leave room for: 5 / 4 / 3 for 1 / 2 / 4
+// accumulator sub-tiles per wave, capped by what the LDS ring allows anyway (one wave per SIMD per workgroup).
+// Without it hipcc lets the tail code take registers the main loop does not need and halves the occupancy.
+constexpr int dma_stage_floats(int BM, int BN, int WK, int KCW) { return (BM + BN) * KCW * WK; }
+constexpr int dma_smem_floats(int BM, int BN, int WM, int WN, int WK, int KCW) {
+    const int ring = 3 * dma_stage_floats(BM, BN, WK, KCW);
+    const int wmn = WM * WN, tm = BM / (32 * WM), tn = BN / (32 * WN);
+    const int tail = (WK - 1) * wmn * tm * tn * 1024 + wmn * 32 * EPI_S;
+    return ring > tail ? ring : tail;
+}
+constexpr int dma_waves(int BM, int BN, int WM, int WN, int WK, int KCW) {
+    const int t = (BM / (32 * WM)) * (BN / (32 * WN));
+    const int by_regs = t == 1 ? 5 : (t == 2 ? WPE2 : 3);
+    const int by_lds = (160 * 1024) / (4 * dma_smem_floats(BM, BN, WM, WN, WK, KCW));
+    return by_regs < by_lds ? by_regs : by_lds;
+}
 template <int BM, int BN, int WAVES_M, int WAVES_N, int WK, int KCW>
-__global__ __launch_bounds__(256) void conv_dma_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, dma_waves(BM, BN, WAVES_M, WAVES_N, WK, KCW))
+void conv_dma_kernel(const ConvParams p) {
     static_assert(WAVES_M * WAVES_N * WK == 4, "4 waves per workgroup");
     constexpr int KS = KCW * WK;
     constexpr int QPR = KS / 4;                        // 16-byte quads per row
@@ -941,28 +1185,29 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvParams p) {
     }
 
     float* sW = smem + RED + wmn * (32 * EPI_S);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                sW[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_S + lr] = acc[i][j][r];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int nb = n0 + (wn * TN + j) * 32 + (lane & 7) * 4;
-            const int mb = m0 + (wm * TM + i) * 32 + (lane >> 3);
+    // One run-time loop over the wave's TM x TN sub-tiles: the (large) tail code exists once, and the compiler
+    // cannot hoist every sub-tile's loads / address arithmetic to the top (which cost 60-130 VGPRs when the loop
+    // was unrolled).  Only the copy of the accumulators into the patch is selected per sub-tile.
 #pragma unroll 1
-            for (int it = 0; it < 4; ++it) {
-                const int m = mb + it * 8;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(sW + ((lane >> 3) + it * 8) * EPI_S + (lane & 7) * 4);
-                if (m < M && nb < p.cout) epilogue4(p, b, m, nb, v);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
+    for (int pi = 0; pi < TM * TN; ++pi) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                if (pi == i * TN + j) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        sW[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_S + lr] = acc[i][j][r];
+                }
+        const int pi_i = pi / TN, pi_j = pi - pi_i * TN;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        patch_tail(p, sW, b, m0 + (wm * TM + pi_i) * 32, n0 + (wn * TN + pi_j) * 32, lane, M);
+        if (p.st_partial) patch_stats(p, sW, b, m0 + (wm * TM + pi_i) * 32, n0 + (wn * TN + pi_j) * 32, lane, M);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
@@ -1136,6 +1381,24 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
     if ((p.Ho - 1) * p.stride - p.padT + 0 >= p.Hin || (p.Wo - 1) * p.stride - p.padL >= p.Win)
         return hipErrorInvalidValue;
 
+    if (p.st_partial && (p.epi != EPI_NONE || p.addend || p.cout <= 2 || (reinterpret_cast<uintptr_t>(p.st_partial) & 15) != 0))
+        return hipErrorInvalidValue;       // statistics are taken over acc + bias, MFMA tiles only
+    {   // 16-byte tail accesses need every row the epilogue touches to be quad aligned
+        auto al = [](const void* q, long ld, long bs) {
+            return q == nullptr || ((reinterpret_cast<uintptr_t>(q) & 15) == 0 && (ld % 4) == 0 && (bs % 4) == 0);
+        };
+        p.epi_vec = al(p.out, p.out_ld, p.out_bs) && al(p.out2, p.out2_ld, p.out2_bs) && al(p.aux0, p.aux0_ld, p.aux0_bs) &&
+                    al(p.aux1, p.aux1_ld, p.aux1_bs) && al(p.aux2, p.aux2_ld, p.aux2_bs) &&
+                    al(p.addend, p.addend_ld, p.addend_bs) && (p.split % 4) == 0 && p.out_cs == 1 && p.epi != EPI_ADD_AUX;
+        // the fast tail addresses rows with 32-bit byte offsets inside one image
+        long max_ld = p.out_ld;
+        for (long l : {(long)p.out2_ld, (long)p.aux0_ld, (long)p.aux1_ld, (long)p.aux2_ld, (long)p.addend_ld}) max_ld = l > max_ld ? l : max_ld;
+        if ((long)p.Ho * p.Wo * max_ld * 4 >= 0x7FFFFF00L) p.epi_vec = 0;
+        if ((reinterpret_cast<uintptr_t>(p.bias) & 15) != 0 || (reinterpret_cast<uintptr_t>(p.lam) & 15) != 0)
+            return hipErrorInvalidValue;
+        if (p.epi == EPI_ADD_AUX_SHRINK && !p.lam) return hipErrorInvalidValue;
+        if (p.addend && p.epi == EPI_LSTC) return hipErrorInvalidValue;      // they share a register slot
+    }
     const bool auto_tile = tile == 0;
     if (tile == 0 && smalln_ok(p)) tile = 7;
     if (tile == 7) {

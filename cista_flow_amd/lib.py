@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcistaflow.so")
+# CF_LIB_PATH: tuning builds of the same library (tools/); the product always loads the in-tree file
+LIB_PATH = os.environ.get("CF_LIB_PATH") or os.path.join(_HERE, "libcistaflow.so")
 
 CF_MODE_CISTA, CF_MODE_EIFLOW, CF_MODE_ERAFT, CF_MODE_IDNET = 0, 1, 2, 3
 CF_WARP_FORWARD, CF_WARP_BACKWARD = 0, 1
@@ -18,7 +19,7 @@ SYMBOLS = [
     "cf_create", "cf_destroy", "cf_last_error", "cf_workspace_bytes", "cf_load_weights",
     "cf_finalize_weights", "cf_warp", "cf_cista_forward", "cf_flow_forward", "cf_step",
     "cf_op_conv2d", "cf_op_instance_norm_relu", "cf_op_corr_lookup", "cf_op_nchw_to_nhwc",
-    "cf_op_nhwc_to_nchw", "cf_profile_enable", "cf_profile_read", "cf_conv_tile_name", "cf_profile_report", "cf_op_conv2d_bench", "cf_events_to_voxel",
+    "cf_op_nhwc_to_nchw", "cf_profile_enable", "cf_profile_read", "cf_conv_tile_name", "cf_profile_report", "cf_op_conv2d_bench", "cf_events_to_voxel", "cf_op_conv2d_inorm_stats",
 ]
 
 
@@ -71,6 +72,9 @@ def load():
     lib.cf_op_conv2d.restype = i
     lib.cf_op_conv2d_bench.argtypes = [fp, i, i, i, i, fp, fp, i, i, i, i, i, i, i, i, i, i, fp, vp, i, C.POINTER(C.c_float), i]
     lib.cf_op_conv2d_bench.restype = i
+    if hasattr(lib, "cf_op_conv2d_inorm_stats"):    # absent only from older tuning builds loaded through CF_LIB_PATH
+        lib.cf_op_conv2d_inorm_stats.argtypes = [fp, i, i, i, i, fp, fp, i, i, i, i, i, i, i, i, i, fp, fp, C.c_float, vp]
+        lib.cf_op_conv2d_inorm_stats.restype = i
     lib.cf_op_instance_norm_relu.argtypes = [fp, fp, i, i, i, i, C.c_float, vp]
     lib.cf_op_instance_norm_relu.restype = i
     lib.cf_op_corr_lookup.argtypes = [fp, fp, fp, fp, i, i, i, i, vp]

@@ -131,6 +131,12 @@ int cf_op_conv2d_bench(const float* in, int B, int Cin, int H, int W, const floa
                        float* out, void* stream, int iters, float* ms_out, int precision);
 int cf_op_instance_norm_relu(const float* x_nhwc, float* out_nhwc, int B, int C, int H, int W, float eps,
                              void* stream);
+/* conv (no activation) whose epilogue also accumulates the InstanceNorm2d statistics of its output
+   (raft_encoder.py:32-36: norm follows every conv of the 'instance' encoders); stats_out [B][Cout][2] =
+   {mean, 1/sqrt(biased var + eps)} as inorm_apply consumes them.  a_mode / tile as cf_op_conv2d. */
+int cf_op_conv2d_inorm_stats(const float* in, int B, int Cin, int H, int W, const float* weight, const float* bias,
+                             int Cout, int KH, int KW, int stride, int padT, int padL, int pad_mode, int a_mode,
+                             int tile, float* out, float* stats_out, float eps, void* stream);
 /* all-pairs correlation + pyramid + lookup (a9/a10): fmaps NHWC [B][h][w][D], coords NCHW [B][2][h][w];
  * out NHWC [B][h][w][4*81] */
 int cf_op_corr_lookup(const float* fmap1, const float* fmap2, const float* coords, float* out, int B, int D, int h,

@@ -106,6 +106,54 @@ CONV_CASES = [
 ]
 
 
+STATS_CASES = [
+    # Cin, Cout, KH, KW, stride, pad, a_mode, tile, H, W   (the encoder convs that feed an InstanceNorm)
+    (64, 64, 3, 3, 1, 1, 0, 0, 48, 64),
+    (64, 96, 3, 3, 2, 1, 0, 0, 48, 64),
+    (64, 96, 1, 1, 2, 0, 0, 0, 48, 64),
+    (96, 128, 3, 3, 1, 1, 0, 0, 13, 19),     # ragged: last 32-pixel patch partly outside the image
+    (128, 128, 3, 3, 1, 1, 0, 20, 24, 32),
+    (128, 128, 3, 3, 1, 1, 0, 22, 24, 32),
+    (64, 64, 3, 3, 1, 1, 0, 23, 21, 37),
+    (64, 64, 3, 3, 1, 1, 0, 26, 40, 40),
+    (64, 64, 3, 3, 1, 1, 0, 2, 21, 37),      # register-staged kernel
+    (64, 96, 3, 3, 1, 1, 0, 9, 21, 37),
+    (5, 64, 7, 7, 2, 3, 2, 0, 64, 80),       # conv1 of the encoders: planar gather mode
+]
+
+
+@pytest.mark.parametrize("case", STATS_CASES)
+def test_conv_fused_inorm_stats(gpu, case):
+    """conv epilogue statistics == mean / biased var of the conv output (InstanceNorm2d, raft_encoder.py:32-36)."""
+    Cin, Cout, KH, KW, stride, pad, a_mode, tile, H, W = case
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(sum(case))
+    B = 3
+    x = torch.randn(B, Cin, H, W, generator=g) + 0.5
+    w = torch.randn(Cout, Cin, KH, KW, generator=g) / (Cin * KH * KW) ** 0.5
+    b = torch.randn(Cout, generator=g) * 2.0
+    ref = ref_conv(x, w, b, stride, pad, pad, 0)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    xin = (x.contiguous() if a_mode == 2 else nhwc(x)).to(gpu)
+    wg, bg = w.to(gpu), b.to(gpu)
+    out = torch.full((B, Ho, Wo, Cout), float("nan"), device=gpu)
+    stats = torch.full((B, Cout, 2), float("nan"), device=gpu)
+    eps = 1e-5
+    rc = L.cf_op_conv2d_inorm_stats(lib.ptr(xin), B, Cin, H, W, lib.ptr(wg), lib.ptr(bg), Cout, KH, KW, stride, pad, pad, 0,
+                                    a_mode, tile, lib.ptr(out), lib.ptr(stats), eps, lib.current_stream_ptr())
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    got = nchw(out.cpu())
+    assert (got - ref).abs().max().item() < 1e-4
+    # statistics of the values the kernel actually stored
+    g64 = got.double()
+    mean = g64.mean(dim=(2, 3))
+    var = g64.var(dim=(2, 3), unbiased=False)
+    st = stats.cpu().double()
+    assert (st[:, :, 0] - mean).abs().max().item() < 1e-6
+    assert ((st[:, :, 1] - 1.0 / torch.sqrt(var + eps)) / (1.0 / torch.sqrt(var + eps))).abs().max().item() < 1e-6
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_nhwc(gpu, case):
     Cin, Cout, KH, KW, stride, padT, padL, pad_mode, tile = case
