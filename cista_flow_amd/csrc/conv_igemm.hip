@@ -458,8 +458,18 @@ __device__ __forceinline__ void patch_stats(const ConvParams& p, const float* sW
     }
 }
 
+// waves per SIMD the register allocation must leave room for (see conv_dma_kernel): what the main loop needs
+// (5 / 4 / 3 / 3 for 1 / 2 / 3 / 4 accumulator sub-tiles), capped by the LDS footprint of the two stage buffers
+constexpr int igemm_waves(int BM, int BN, int WM, int WN, int WK, int KCW) {
+    const int t = (BM / (32 * WM)) * (BN / (32 * WN));
+    const int by_regs = t == 1 ? 5 : (t == 2 ? 4 : 3);
+    const int stage2 = 2 * (BM + BN) * (KCW * WK + 4);
+    const int tail = (WK - 1) * WM * WN * t * 1024 + WM * WN * 32 * 36;
+    const int by_lds = (160 * 1024) / (4 * (stage2 > tail ? stage2 : tail) + 1024);
+    return by_regs < by_lds ? by_regs : by_lds;
+}
 template <int BM, int BN, int WAVES_M, int WAVES_N, int WK, int AMODE, int PREC, int KCW = 16>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, igemm_waves(BM, BN, WAVES_M, WAVES_N, WK, KCW)) void conv_igemm_kernel(const ConvParams p) {
     static_assert(KCW == 16 || KCW == 32, "KCW");
     static_assert(KCW == 16 || AMODE == A_NHWC, "wide stages only for the plain NHWC read");
     static_assert(WAVES_M * WAVES_N * WK == 4, "4 waves per workgroup");
