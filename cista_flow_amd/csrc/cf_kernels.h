@@ -89,6 +89,7 @@ struct ConvParams {
     // fused InstanceNorm statistics (EPI_NONE only): every 32-pixel x cout patch of the output adds its fp64
     // {sum, sum of squares} of v = acc + bias to st_partial[b][ceil(M/32)][cout][2]; launch_inorm_final folds them
     double* st_partial;
+    long long* stamp;   // -DCF_STAMP builds only (tools/stamp_probe.py): per-wave cycle stamps of conv_dma_kernel
     int  epi_vec;       // set by launch_conv: out / out2 / aux / addend rows are 16-byte aligned (dwordx4 tail)
 };
 

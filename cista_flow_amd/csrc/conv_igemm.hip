@@ -243,6 +243,11 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned of
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
 }
 
+// CLS = which aux slots the epilogue kind can touch (so that only those are allocated): 0 none, 1 aux0,
+// 2 aux0 + aux1 + addend (GRU, and any kind with an addend), 3 all four (LSTC).  EB = quads of a lane whose loads are
+// in flight together: the tail is a chain of dependent global round trips (~0.8 us each under load), so EB = 4
+// leaves one exposed latency per sub-tile instead of four.
+template <int EB, int CLS>
 __device__ __forceinline__ void patch_tail_fast(const ConvParams& p, const float* sW, int b, int mrow0, int nbase, int lane,
                                                 int M) {
     const int n = nbase + (lane & 7) * 4;
@@ -265,38 +270,36 @@ __device__ __forceinline__ void patch_tail_fast(const ConvParams& p, const float
     const bool sp_hi = epi == EPI_TANH_RELU_SPLIT && n >= p.split;
     const unsigned n4_hi = 4u * (unsigned)(n - p.split);
 #pragma unroll
-    for (int h = 0; h < 4; h += EPI_BATCH) {
-        EpiAux x[EPI_BATCH];
+    for (int h = 0; h < 4; h += EB) {
+        EpiAux x[EB];
 #pragma unroll
-        for (int it = 0; it < EPI_BATCH; ++it) {
+        for (int it = 0; it < EB; ++it) {
             const int m = mb + (h + it) * 8;
             const bool ok = m < M;
             const unsigned um = (unsigned)m;
-            if (has_add || epi == EPI_LSTC) x[it].a2 = buf_load4(r_a2, ok ? um * ld_a2 + n4 : BUF_OOB, 0);
-            switch (epi) {
-                case EPI_SUB_FROM_AUX:
-                case EPI_ADD_AUX_SHRINK:
-                case EPI_RELU_ADD_AUX:
-                case EPI_RELU_ADD_AUX_RELU:
-                    x[it].a0 = buf_load4(r_a0, ok ? um * (4u * (unsigned)p.aux0_ld) + n4 : BUF_OOB, 0);
-                    break;
-                case EPI_LSTC:
-                    x[it].a0 = buf_load4(r_a0, ok ? um * (4u * (unsigned)p.aux0_ld) + n4 : BUF_OOB, 0);
-                    x[it].a3 = buf_load4(r_a0, ok ? um * (4u * (unsigned)p.aux0_ld) + n4 + 4u * (unsigned)p.split : BUF_OOB, 0);
-                    x[it].a1 = buf_load4(r_a1, ok ? um * (4u * (unsigned)p.aux1_ld) + n4 : BUF_OOB, 0);
-                    break;
-                case EPI_GRU_ZR:
+            const unsigned o0 = ok ? um * (4u * (unsigned)p.aux0_ld) + n4 : BUF_OOB;
+            if constexpr (CLS == 1) {
+                x[it].a0 = buf_load4(r_a0, o0, 0);
+            } else if constexpr (CLS == 2) {
+                if (has_add) x[it].a2 = buf_load4(r_a2, ok ? um * ld_a2 + n4 : BUF_OOB, 0);
+                if (epi == EPI_GRU_ZR) {
                     x[it].a0 = buf_load4(r_a0, (ok && zr_hi) ? um * (4u * (unsigned)p.aux0_ld) + n4_hi : BUF_OOB, 0);
-                    break;
-                case EPI_GRU_Q:
-                    x[it].a0 = buf_load4(r_a0, ok ? um * (4u * (unsigned)p.aux0_ld) + n4 : BUF_OOB, 0);
+                } else if (epi == EPI_GRU_Q) {
+                    x[it].a0 = buf_load4(r_a0, o0, 0);
                     x[it].a1 = buf_load4(r_a1, ok ? um * (4u * (unsigned)p.aux1_ld) + n4 : BUF_OOB, 0);
-                    break;
-                default: break;
+                } else if (epi == EPI_SUB_FROM_AUX || epi == EPI_ADD_AUX_SHRINK || epi == EPI_RELU_ADD_AUX ||
+                           epi == EPI_RELU_ADD_AUX_RELU) {
+                    x[it].a0 = buf_load4(r_a0, o0, 0);
+                }
+            } else if constexpr (CLS == 3) {
+                x[it].a0 = buf_load4(r_a0, o0, 0);
+                x[it].a3 = buf_load4(r_a0, ok ? um * (4u * (unsigned)p.aux0_ld) + n4 + 4u * (unsigned)p.split : BUF_OOB, 0);
+                x[it].a1 = buf_load4(r_a1, ok ? um * (4u * (unsigned)p.aux1_ld) + n4 : BUF_OOB, 0);
+                x[it].a2 = buf_load4(r_a2, ok ? um * ld_a2 + n4 : BUF_OOB, 0);
             }
         }
 #pragma unroll
-        for (int it = 0; it < EPI_BATCH; ++it) {
+        for (int it = 0; it < EB; ++it) {
             const int m = mb + (h + it) * 8;
             const bool ok = m < M;
             const unsigned um = (unsigned)m;
@@ -305,9 +308,11 @@ __device__ __forceinline__ void patch_tail_fast(const ConvParams& p, const float
             f32x4 v, o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = acc[e] + bias4[e];
-            if (has_add) {
+            if constexpr (CLS == 2) {
+                if (has_add) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += a.a2[e];
+                    for (int e = 0; e < 4; ++e) v[e] += a.a2[e];
+                }
             }
             o = v;
             bool to_out = true;
@@ -325,49 +330,70 @@ __device__ __forceinline__ void patch_tail_fast(const ConvParams& p, const float
                     for (int e = 0; e < 4; ++e) o[e] = tanhf(v[e]);
                     break;
                 case EPI_SUB_FROM_AUX:
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = a.a0[e] - v[e];
+                    if constexpr (CLS == 1 || CLS == 2) {
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = a.a0[e] - v[e];
+                        break;
+                    }
                     break;
                 case EPI_ADD_AUX_SHRINK:
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float t = v[e] + a.a0[e];
-                        o[e] = fmaxf(t - lam4[e], 0.f) - fmaxf(-t - lam4[e], 0.f);
+                    if constexpr (CLS == 1 || CLS == 2) {
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float t = v[e] + a.a0[e];
+                            o[e] = fmaxf(t - lam4[e], 0.f) - fmaxf(-t - lam4[e], 0.f);
+                        }
+                        break;
                     }
                     break;
                 case EPI_RELU_ADD_AUX:
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = fmaxf(v[e], 0.f) + a.a0[e];
+                    if constexpr (CLS == 1 || CLS == 2) {
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = fmaxf(v[e], 0.f) + a.a0[e];
+                        break;
+                    }
                     break;
                 case EPI_RELU_ADD_AUX_RELU:
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = fmaxf(a.a0[e] + fmaxf(v[e], 0.f), 0.f);
+                    if constexpr (CLS == 1 || CLS == 2) {
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = fmaxf(a.a0[e] + fmaxf(v[e], 0.f), 0.f);
+                        break;
+                    }
                     break;
                 case EPI_LSTC: {
-                    // aux0 = sigmoid gates [px][2*split] (i | f), aux1 = z0, aux2 = c_prev; out = z, out2 = c
-                    f32x4 c;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        c[e] = a.a3[e] * a.a2[e] + a.a0[e] * a.a1[e];
-                        o[e] = sigmoidf_(v[e]) * tanhf(c[e]);
+                    if constexpr (CLS == 3) {
+                        // aux0 = sigmoid gates [px][2*split] (i | f), aux1 = z0, aux2 = c_prev; out = z, out2 = c
+                        f32x4 c;
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            c[e] = a.a3[e] * a.a2[e] + a.a0[e] * a.a1[e];
+                            o[e] = sigmoidf_(v[e]) * tanhf(c[e]);
+                        }
+                        buf_store4(r_out2, ok ? um * (4u * (unsigned)p.out2_ld) + n4 : BUF_OOB, c);
+                    } break;
                     }
-                    buf_store4(r_out2, ok ? um * (4u * (unsigned)p.out2_ld) + n4 : BUF_OOB, c);
-                } break;
+                    break;
                 case EPI_GRU_ZR:
-                    if (zr_hi) {
-                        to_out = false;
-                        f32x4 r;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) r[e] = sigmoidf_(v[e]) * a.a0[e];
-                        buf_store4(r_out2, ok ? um * (4u * (unsigned)p.out2_ld) + n4_hi : BUF_OOB, r);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = sigmoidf_(v[e]);
+                    if constexpr (CLS == 2) {
+                        if (zr_hi) {
+                            to_out = false;
+                            f32x4 r;
+    #pragma unroll
+                            for (int e = 0; e < 4; ++e) r[e] = sigmoidf_(v[e]) * a.a0[e];
+                            buf_store4(r_out2, ok ? um * (4u * (unsigned)p.out2_ld) + n4_hi : BUF_OOB, r);
+                        } else {
+    #pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = sigmoidf_(v[e]);
+                        }
+                        break;
                     }
                     break;
                 case EPI_GRU_Q:
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (1.f - a.a0[e]) * a.a1[e] + a.a0[e] * tanhf(v[e]);
+                    if constexpr (CLS == 2) {
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (1.f - a.a0[e]) * a.a1[e] + a.a0[e] * tanhf(v[e]);
+                        break;
+                    }
                     break;
                 case EPI_TANH_RELU_SPLIT:
                     if (sp_hi) {
@@ -403,7 +429,13 @@ __device__ __forceinline__ void patch_tail_fast(const ConvParams& p, const float
 // generic tail: any alignment, partial quads, strided outputs (out_cs != 1), EPI_ADD_AUX
 __device__ __forceinline__ void patch_tail(const ConvParams& p, const float* sW, int b, int mrow0, int nbase, int lane, int M) {
     if (p.epi_vec && nbase + 32 <= p.cout) {      // wave-uniform
-        patch_tail_fast(p, sW, b, mrow0, nbase, lane, M);
+        const int epi = p.epi;
+        const bool one_aux = epi == EPI_SUB_FROM_AUX || epi == EPI_ADD_AUX_SHRINK || epi == EPI_RELU_ADD_AUX ||
+                             epi == EPI_RELU_ADD_AUX_RELU;
+        if (epi == EPI_LSTC) patch_tail_fast<1, 3>(p, sW, b, mrow0, nbase, lane, M);
+        else if (p.addend || epi == EPI_GRU_ZR || epi == EPI_GRU_Q) patch_tail_fast<2, 2>(p, sW, b, mrow0, nbase, lane, M);
+        else if (one_aux) patch_tail_fast<4, 1>(p, sW, b, mrow0, nbase, lane, M);
+        else patch_tail_fast<4, 0>(p, sW, b, mrow0, nbase, lane, M);
         return;
     }
     const int nb = nbase + (lane & 7) * 4;
@@ -963,6 +995,10 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, int WK, int KCW>
 __global__ __launch_bounds__(256, dma_waves(BM, BN, WAVES_M, WAVES_N, WK, KCW))
 void conv_dma_kernel(const ConvParams p) {
     static_assert(WAVES_M * WAVES_N * WK == 4, "4 waves per workgroup");
+#ifdef CF_STAMP
+    const long long t_begin = __builtin_readcyclecounter();
+    long long st_wait = 0, st_bar = 0, st_issue = 0;
+#endif
     constexpr int KS = KCW * WK;
     constexpr int QPR = KS / 4;                        // 16-byte quads per row
     constexpr int RPB = (16 / QPR) > 0 ? (16 / QPR) : 1;   // rows per 256-byte bank row
@@ -1103,13 +1139,21 @@ void conv_dma_kernel(const ConvParams p) {
         for (int j = 0; j < A_IT; ++j) {
             if ((256 * j + 64 * wave) < A_SLOTS) {      // wave-uniform
                 const unsigned off = a_pix[j] < 0 ? BUF_OOB : (unsigned)a_pix[j] * ld4 + a_qoff[j];
+#ifndef CF_EXP_NOLOAD
                 dma16_to_lds(rs, base + (256 * j + 64 * wave) * 4, off, so);
+#else
+                asm volatile("" ::"v"(off), "s"(so));
+#endif
             }
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
             if ((256 * it + 64 * wave) < B_SLOTS)
+#ifndef CF_EXP_NOLOAD
                 dma16_to_lds(b_rsrc, base + BM * KS + (256 * it + 64 * wave) * 4, b_off[it], (unsigned)it_k * 4u);
+#else
+                asm volatile("" ::"v"(b_off[it]));
+#endif
         }
         // ---- advance the (wave-uniform) iterator ----
         it_k += KS;
@@ -1142,12 +1186,29 @@ void conv_dma_kernel(const ConvParams p) {
     if (nck > 1) issue_stage(1);
 
     int rbuf = 0, wbuf = 2;
+#ifdef CF_STAMP
+    const long long t_loop_begin = __builtin_readcyclecounter();
+#endif
     for (int ck = 0; ck < nck; ++ck) {
         // stage ck has landed once at most the loads of stage ck+1 are still in flight
+#ifdef CF_STAMP
+        const long long t0 = __builtin_readcyclecounter();
+#endif
         if (ck + 1 < nck) wait_vmcnt_le(nl);
         else wait_vmcnt0();
+#ifdef CF_STAMP
+        const long long t1 = __builtin_readcyclecounter();
+#endif
         raw_barrier();
+#ifdef CF_STAMP
+        const long long t2 = __builtin_readcyclecounter();
+#endif
         if (ck + 2 < nck) issue_stage(wbuf);
+#ifdef CF_STAMP
+        st_wait += t1 - t0;
+        st_bar += t2 - t1;
+        st_issue += __builtin_readcyclecounter() - t2;
+#endif
         const char* sbase = reinterpret_cast<const char*>(smem + rbuf * STAGE);
 #pragma unroll
         for (int ks = 0; ks < KCW / 8; ++ks) {
@@ -1161,12 +1222,20 @@ void conv_dma_kernel(const ConvParams p) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
+                    for (int j = 0; j < TN; ++j) {
+#ifndef CF_EXP_NOMFMA
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+#else
+                        acc[i][j][s] += af[i][s] * bf[j][s];
+#endif
+                    }
         }
         rbuf = rbuf == NBUF - 1 ? 0 : rbuf + 1;
         wbuf = wbuf == NBUF - 1 ? 0 : wbuf + 1;
     }
+#ifdef CF_STAMP
+    const long long t_loop_end = __builtin_readcyclecounter();
+#endif
     wait_lgkm0();
     raw_barrier();          // every wave is done reading the ring before it is reused below
 
@@ -1219,6 +1288,13 @@ void conv_dma_kernel(const ConvParams p) {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+#ifdef CF_STAMP
+    if (p.stamp && lane == 0) {      // [wait, barrier, issue, prologue, stages, loop, tail, -] cycles of this wave
+        long long* q = p.stamp + ((long)blockIdx.x * 4 + wave) * 8;
+        q[0] = st_wait; q[1] = st_bar; q[2] = st_issue; q[3] = t_loop_begin - t_begin; q[4] = nck;
+        q[5] = t_loop_end - t_loop_begin; q[6] = __builtin_readcyclecounter() - t_loop_end; q[7] = 0;
+    }
+#endif
 }
 
 template <int BM, int BN, int WM, int WN, int WK, int KCW>
@@ -1360,6 +1436,9 @@ static int default_dma() {
 
 hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int tile, int* tile_used) {
     ConvParams p = p_in;
+#ifdef CF_STAMP
+    { const char* e = getenv("CF_STAMP_BUF"); p.stamp = e ? reinterpret_cast<long long*>(strtoull(e, nullptr, 10)) : nullptr; }
+#endif
     if (p.sched < 0) p.sched = default_sched();
     // ---- host-side shape checks: a bad descriptor must never reach the GPU ----
     if (p.Ktot <= 0 || (p.Ktot % KC) != 0 || p.cout <= 0 || batch <= 0 || p.Ho <= 0 || p.Wo <= 0)

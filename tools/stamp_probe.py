@@ -1,17 +1,36 @@
-import os, sys
+#!/usr/bin/env python3
+"""In-kernel cycle accounting of conv_dma_kernel (tuning tool, GPU box only).
+
+Needs a -DCF_STAMP build of the library:
+    hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -DCF_STAMP -o build_var/lib_stamp.so cista_flow_amd/csrc/*.hip
+    CF_LIB_PATH=$PWD/build_var/lib_stamp.so python tools/stamp_probe.py
+Every wave records (s_memtime) the cycles it spent waiting for its DMA (vmcnt), at the stage barrier, issuing the
+next stage, and the lengths of its prologue / main loop / tail.  The stamps themselves cost ~100 cycles each.
+"""
+import os
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
-import torch
-buf = torch.zeros(8 * 4 * 20000, dtype=torch.int64, device="cuda")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import torch  # noqa: E402
+
+buf = torch.zeros(8 * 4 * 40000, dtype=torch.int64, device="cuda")
 os.environ["CF_STAMP_BUF"] = str(buf.data_ptr())
-import conv_bench
-for idx, tile in [(0, 9), (0, 4), (1, 8), (10, 1)]:
+import conv_bench  # noqa: E402
+
+CASES = os.environ.get("CASES", "cista.D:26,cista.D:23,cista.P:23,gates:26,gru.zr:20,gru.q:22,layer1:26")
+for case in CASES.split(","):
+    name, tile = case.split(":")
+    shape = [s for s in conv_bench.SHAPES if s[0].startswith(name)][0]
     buf.zero_()
-    r = conv_bench.run(conv_bench.SHAPES[idx], tile, 3)
+    r = conv_bench.run(shape, int(tile), 3)
     torch.cuda.synchronize()
     d = buf.view(-1, 8).cpu()
-    d = d[d[:, 5] > 0].double()
-    n = d[:, 5].mean().item()
-    m = d[:, :5].mean(0) / n
-    print(conv_bench.SHAPES[idx][0], "tile", tile, "us %.1f" % r[0], "stages %d" % n,
-          "per-stage cycles: load-issue %.0f | lds-read+mfma %.0f | vmcnt wait %.0f | lds-store %.0f | barrier %.0f | total %.0f" % (m[0], m[1], m[2], m[3], m[4], m.sum()))
+    d = d[d[:, 4] > 0].double()
+    n = d[:, 4].mean().item()
+    m = d.mean(0)
+    comp = (m[5] - m[0] - m[1] - m[2]) / n
+    print("%-34s tile %2d  %7.1f us %5.1f TF | stages %3d | per stage: vmcnt-wait %4.0f  barrier %4.0f  issue %4.0f  lds+mfma %4.0f"
+          " | prologue %6.0f  loop %7.0f  tail %6.0f cycles" % (shape[0], int(tile), r[0], r[1], n, m[0] / n, m[1] / n, m[2] / n,
+                                                              comp, m[3], m[5], m[6]), flush=True)
