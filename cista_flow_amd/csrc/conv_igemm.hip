@@ -1372,14 +1372,131 @@ __global__ __launch_bounds__(256) void conv_smalln_kernel(const ConvParams p, in
     }
 }
 
+// 3x3 / stride 1 / pad 1 specialisation of the small-N conv (final_conv 64->1, FlowHead.conv2 256->2): HBM-bound.
+// The generic kernel above re-reads every input quad 9x and every weight quad per tap through the L1 (64 B/clk/CU),
+// which is what bounded it (~1.3 TB/s).  Here a lane keeps its weight quads (COUT x 9) in registers and walks down
+// a column of RY output rows with a 3-row register window, so each input quad is loaded 3x (the x taps) instead
+// of 9x and no weight is reloaded.  lpp lanes share a pixel (4 channels each) and fold with xor-shuffles.
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_small3x3_kernel(const ConvParams p, int lpp, int RY) {
+    const int tid = threadIdx.x;
+    const int g = tid / lpp;                 // column slot inside the workgroup
+    const int ppw = 256 / lpp;               // columns per workgroup
+    const int c0 = (tid - g * lpp) * 4;
+    const int b = blockIdx.z;
+    const int H = p.Hin, W = p.Win;
+    const int x = blockIdx.x * ppw + g;
+    const int y0 = blockIdx.y * RY;
+    const bool live = x < W;
+    const int ld = p.seg_ld[0];
+    const float* src = p.in[0] + (long)b * p.seg_bs[0] + c0;
+    f32x4 w[COUT][9];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) w[co][t] = *reinterpret_cast<const f32x4*>(p.w + (long)co * p.Ktot + t * p.cin_pad + c0);
+    // column offsets of the three x taps (reflect / zero padding)
+    int xo[3];
+    bool xok[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        int ix = x + kx - 1;
+        bool ok = live;
+        if (p.pad_mode == 1) ix = reflect_idx(ix, W);
+        else ok = ok && ix >= 0 && ix < W;
+        xok[kx] = ok;
+        xo[kx] = ok ? ix : 0;
+    }
+    auto load_row = [&](int y, f32x4 (&r)[3]) __attribute__((always_inline)) {
+        int iy = y;
+        bool ok = true;
+        if (p.pad_mode == 1) iy = reflect_idx(iy, H);
+        else ok = iy >= 0 && iy < H;
+        const float* row = src + (long)(ok ? iy : 0) * W * ld;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok && xok[kx]) v = *reinterpret_cast<const f32x4*>(row + (long)xo[kx] * ld);
+            r[kx] = v;
+        }
+    };
+    f32x4 r0[3], r1[3], r2[3], r3[3];
+    load_row(y0 - 1, r0);
+    load_row(y0, r1);
+    load_row(y0 + 1, r2);
+    const int yend = (y0 + RY < H) ? y0 + RY : H;
+    for (int y = y0; y < yend; ++y) {
+        load_row(y + 2, r3);                 // one row ahead of the one this iteration consumes
+        float acc[COUT];
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            float a = 0.f;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    a += r0[kx][e] * w[co][kx][e] + r1[kx][e] * w[co][3 + kx][e] + r2[kx][e] * w[co][6 + kx][e];
+            }
+            for (int off = lpp >> 1; off > 0; off >>= 1) a += __shfl_xor(a, off);
+            acc[co] = a;
+        }
+        if (live && c0 == 0) {
+            const int m = y * W + x;
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) {
+                float v = acc[co] + (p.bias ? p.bias[co] : 0.f);
+                const long ooff = (long)b * p.out_bs + (long)m * p.out_ld + (long)co * p.out_cs;
+                if (p.epi == EPI_SIGMOID) v = sigmoidf_(v);
+                else if (p.epi == EPI_RELU) v = fmaxf(v, 0.f);
+                else if (p.epi == EPI_TANH) v = tanhf(v);
+                else if (p.epi == EPI_ADD_AUX) v += p.aux0[(long)b * p.aux0_bs + (long)m * p.aux0_ld + (long)co * p.aux0_cs];
+                p.out[ooff] = v;
+            }
+        }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            r0[kx] = r1[kx];
+            r1[kx] = r2[kx];
+            r2[kx] = r3[kx];
+        }
+    }
+}
+
+static int default_small3x3() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("CF_SMALL3X3");
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
+
 static bool smalln_ok(const ConvParams& p) {
     if (p.a_mode != A_NHWC || p.nseg != 1 || p.cout > 2 || p.w_bs != 0) return false;
     if (p.cin_pad != 64 && p.cin_pad != 128 && p.cin_pad != 256) return false;
     return p.epi == EPI_NONE || p.epi == EPI_SIGMOID || p.epi == EPI_RELU || p.epi == EPI_TANH || p.epi == EPI_ADD_AUX;
 }
 
-static hipError_t launch_smalln(const ConvParams& p, int batch, hipStream_t s) {
+static bool small3x3_ok(const ConvParams& p) {
+    return p.KH == 3 && p.KW == 3 && p.stride == 1 && p.padT == 1 && p.padL == 1 && p.Ho == p.Hin && p.Wo == p.Win && p.Hin >= 3 &&
+           p.Win >= 3;
+}
+
+// force3x3: tile 15 (tests); otherwise the window kernel is used where it pays: the full-resolution final conv
+// (the 1/8-resolution FlowHead conv is launch-latency-bound either way)
+static hipError_t launch_smalln(const ConvParams& p, int batch, hipStream_t s, bool force3x3) {
     const int lpp = p.cin_pad / 4;
+    if (force3x3 && !small3x3_ok(p)) return hipErrorInvalidValue;
+    if (small3x3_ok(p) && (force3x3 || (default_small3x3() && (long)p.Hin * p.Win * batch >= 100000))) {
+        const int ppw = 256 / lpp;
+        // rows per workgroup: long columns amortise the 2-row warm-up, but keep >= ~1000 workgroups in flight
+        int RY = 12;
+        while (RY > 3 && (long)((p.Win + ppw - 1) / ppw) * ((p.Hin + RY - 1) / RY) * batch < 1024) RY -= 3;
+        dim3 grid((p.Win + ppw - 1) / ppw, (p.Hin + RY - 1) / RY, batch);
+        if (p.cout == 1) hipLaunchKernelGGL(conv_small3x3_kernel<1>, grid, dim3(256), 0, s, p, lpp, RY);
+        else hipLaunchKernelGGL(conv_small3x3_kernel<2>, grid, dim3(256), 0, s, p, lpp, RY);
+        return hipGetLastError();
+    }
     const int ppw = 256 / lpp;
     const int M = p.Ho * p.Wo;
     dim3 grid((M + ppw - 1) / ppw, batch);
@@ -1490,10 +1607,10 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
     }
     const bool auto_tile = tile == 0;
     if (tile == 0 && smalln_ok(p)) tile = 7;
-    if (tile == 7) {
+    if (tile == 7 || tile == 15) {
         if (!smalln_ok(p)) return hipErrorInvalidValue;
         if (tile_used) *tile_used = 7;
-        return launch_smalln(p, batch, s);
+        return launch_smalln(p, batch, s, tile == 15);
     }
     if (tile == 0) {
         // Pick the largest tile that still yields >= ~2 workgroups per CU (measured with tools/conv_bench.py on

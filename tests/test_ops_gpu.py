@@ -79,6 +79,10 @@ CONV_CASES = [
     (256, 2, 3, 3, 1, 1, 1, 0, 7),     # ... and through the VALU small-N kernel explicitly
     (64, 1, 3, 3, 1, 1, 1, 1, 7),
     (128, 2, 3, 3, 1, 1, 1, 0, 7),
+    (256, 2, 3, 3, 1, 1, 1, 0, 15),    # ... and its 3x3 register-window form (weights + 3 input rows in registers)
+    (64, 1, 3, 3, 1, 1, 1, 1, 15),
+    (128, 2, 3, 3, 1, 1, 1, 1, 15),
+    (64, 2, 3, 3, 1, 1, 1, 0, 15),
     (128, 128, 3, 3, 1, 1, 1, 0, 8),   # intra-workgroup split-K tiles (32x32xK4, 32x64xK2)
     (64, 96, 3, 3, 1, 1, 1, 1, 8),
     (256, 126, 1, 5, 1, 0, 2, 0, 8),
