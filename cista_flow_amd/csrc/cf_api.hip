@@ -83,7 +83,7 @@ struct cf_handle {
     Arena arena;
     void* arena_mem = nullptr;
     // CISTA
-    float *xcat = nullptr, *x1 = nullptr, *ifbuf = nullptr, *z0 = nullptr, *xt = nullptr, *recx = nullptr, *gbuf = nullptr,
+    float *xcat = nullptr, *x1 = nullptr, *ifbuf = nullptr, *z0 = nullptr, *xt = nullptr, *recx = nullptr,
           *up = nullptr, *zeros = nullptr;
     // wrapper
     float *warpedI = nullptr, *zwarp = nullptr;
@@ -214,7 +214,6 @@ static void setup_buffers(cf_handle* H_) {
     s.z0 = a.f(B * hw * 2 * bc);
     s.xt = a.f(B * hw * bc);
     s.recx = a.f(B * hw * bc);
-    s.gbuf = a.f(B * hw * 4 * bc);
     s.up = a.f(B * HW * bc);
     s.warpedI = a.f(B * HW);
     s.zwarp = a.f(B * hw * 2 * bc);
@@ -364,7 +363,8 @@ struct CinSlice { int begin, count, dst; int accum = 0; };
 // (used to split a layer into its iteration-invariant and per-iteration parts); with_bias=false drops the bias.
 static int pack_conv(cf_handle* h, const std::string& key, const std::string& prefix, bool gather, int row0,
                      int total_rows, const std::string& bn_prefix, hipStream_t st,
-                     const std::vector<CinSlice>& slices = {}, int packed_cin = 0, bool with_bias = true) {
+                     const std::vector<CinSlice>& slices = {}, int packed_cin = 0, bool with_bias = true,
+                     int interleave = 0) {
     const RawWeight* wt = find_raw(h, prefix + ".weight");
     const RawWeight* bs = find_raw(h, prefix + ".bias");
     if (!wt || wt->shape.size() != 4) return h->fail(CF_ERR_WEIGHT, "missing or non-4D weight: " + prefix + ".weight");
@@ -405,7 +405,7 @@ static int pack_conv(cf_handle* h, const std::string& key, const std::string& pr
     const float* bsrc = (bs && with_bias) ? bs->ptr : nullptr;
     if (slices.empty()) {
         CF_HIP(h, launch_pack_weight(wt->ptr, pc.w, Cout, Cin, KH, KW, pc.cin_pad, pc.Ktot, row0, gather ? 1 : 0, 0, 0, 0, 0, bw,
-                                     bb, bm, bv, 1e-5f, bsrc, pc.bias, st));
+                                     bb, bm, bv, 1e-5f, bsrc, pc.bias, st, interleave));
     } else {
         for (const CinSlice& sl : slices)
             CF_HIP(h, launch_pack_weight(wt->ptr, pc.w, Cout, Cin, KH, KW, pc.cin_pad, pc.Ktot, row0, gather ? 1 : 0, sl.begin,
@@ -477,7 +477,8 @@ extern "C" int cf_finalize_weights(cf_handle* h, void* stream) {
         if ((rc = C("D", "lista_blocks.0.D.conv2d", false))) return rc;
         if ((rc = C("P", "lista_blocks.0.P.conv2d", false))) return rc;
         if ((rc = C("Dg", "Dg.conv.conv2d", false))) return rc;
-        if ((rc = C("Gates", "Dg.recurrent_block.Gates", false))) return rc;
+        // ConvLSTM gates: rows interleaved so that the four gates of a hidden channel form one quad of the conv tail
+        if ((rc = pack_conv(h, "cista.Gates", cn + "Dg.recurrent_block.Gates", false, 0, 0, "", st, {}, 0, true, 4))) return rc;
         if ((rc = C("upsamp", "upsamp_conv.conv2d", false))) return rc;
         if ((rc = C("final", "final_conv.conv2d", false))) return rc;
         const RawWeight* lam = find_raw(h, cn + "lista_blocks.0.Lambda");
@@ -766,6 +767,9 @@ static int cista_forward(cf_handle* h, const float* ev, const float* img, const 
     const int B = h->B, H = h->H, W = h->W, hh = h->h, ww = h->w, bc = h->bc, bins = h->cfg.num_bins;
     const long HW = (long)H * W, hw = (long)hh * ww;
     const int c2 = 2 * bc;
+    // the new states are written by conv tails while the previous ones are still being read (3x3 halos)
+    if ((z_prev && z_prev == z_out) || (c_prev && c_prev == c_out) || (h_prev && h_prev == h_out) || (cc_prev && cc_prev == cc_out))
+        return h->fail(CF_ERR_ARG, "cista_forward: output states must not alias the previous states");
     if (!z_prev) z_prev = h->zeros;
     if (!c_prev) c_prev = h->zeros;
     if (!h_prev) h_prev = h->zeros;
@@ -815,12 +819,12 @@ static int cista_forward(cf_handle* h, const float* ev, const float* img, const 
         ConvParams d = nhwc_conv(h->conv["cista.Dg"], {{z_out, c2, c2, hw * c2}}, hh, ww, hh, ww, 1, 1, 1, 1, h->recx, bc,
                                  hw * bc, EPI_RELU);
         CF_HIP(h, run_conv(h, d, B, st));
+        // gates conv with the cell update in its tail (rows packed gate-interleaved): no [B,4*bc,h,w] gate tensor
         ConvParams g = nhwc_conv(h->conv["cista.Gates"], {{h->recx, bc, bc, hw * bc}, {h_prev, bc, bc, hw * bc}}, hh, ww,
-                                 hh, ww, 1, 1, 1, 1, h->gbuf, 4 * bc, hw * 4 * bc, EPI_LSTM_ACT);
-        g.split = 3 * bc;
+                                 hh, ww, 1, 1, 1, 1, h_out, bc, hw * bc, EPI_LSTM_CELL);
+        set_aux0(g, cc_prev ? cc_prev : h->zeros, bc, hw * bc);
+        set_out2(g, cc_out, bc, hw * bc);
         CF_HIP(h, run_conv(h, g, B, st));
-        CF_HIP(h, launch_lstm_cell(h->gbuf, 4 * bc, hw * 4 * bc, cc_prev, bc, hw * bc, h_out, bc, hw * bc, cc_out, bc,
-                                   hw * bc, B, (int)hw, bc, st));
     }
     // upsample x2 + reflect pad + conv + relu ; final conv + sigmoid   e2v_model.py:94-96
     {

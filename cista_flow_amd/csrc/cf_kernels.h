@@ -39,6 +39,8 @@ enum Epi {
     EPI_LSTM_ACT = 13,       // n < split: sigmoid ; else tanh         (ConvLSTM gate pre-activation)
     EPI_ADD_AUX = 14,        // out = v + aux0                         (coords1 += delta_flow)
     EPI_BIAS_SCALE = 15,     // out = (acc + bias) * scale             (ERAFT: .25 * mask(net))
+    EPI_LSTM_CELL = 16,      // ConvLSTM tail on gate-interleaved rows (quad = in | remember | out | cell of one hidden
+                             // channel): c = sig(f)*aux0 + sig(i)*tanh(g); out = sig(o)*tanh(c); out2 = c   (base_layers.py:117-132)
 };
 
 struct ConvParams {
@@ -112,7 +114,8 @@ hipError_t launch_pack_weight(const float* src, float* dst, int Cout, int Cin, i
                               int accum,
                               const float* bn_w, const float* bn_b, const float* bn_mean,
                               const float* bn_var, float bn_eps,
-                              const float* bias_src, float* bias_dst, hipStream_t s);
+                              const float* bias_src, float* bias_dst, hipStream_t s, int interleave = 0);
+// interleave = G > 1: output channel g*(Cout/G) + j is stored as row j*G + g (gate-interleaved rows, EPI_LSTM_CELL)
 
 // ---------------------------------------------------------------------------
 // HBM-bound kernels
@@ -141,11 +144,6 @@ hipError_t launch_inorm_stats(const float* x, int ld, long bs, int B, int HW, in
 hipError_t launch_inorm_apply(const float* x, int ld, long bs, const float* stats,
                               const float* res, int res_ld, long res_bs, const float* res_stats,
                               float* out, int out_ld, long out_bs, int B, int HW, int C, hipStream_t s);
-
-// ConvLSTM cell: g = [px][4*Ch] pre-activated (i,f,o sigmoid | cell tanh)
-hipError_t launch_lstm_cell(const float* g, int g_ld, long g_bs, const float* c_prev, int cp_ld, long cp_bs,
-                            float* h_out, int h_ld, long h_bs, float* c_out, int c_ld, long c_bs,
-                            int B, int HW, int Ch, hipStream_t s);
 
 // correlation pyramid: dst[b][i][y][x] = avg 2x2 of src
 hipError_t launch_corr_pool(const float* src, float* dst, long rows, int Hs, int Ws, hipStream_t s);

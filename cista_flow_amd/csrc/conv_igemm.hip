@@ -247,6 +247,10 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned of
 // 2 aux0 + aux1 + addend (GRU, and any kind with an addend), 3 all four (LSTC).  EB = quads of a lane whose loads are
 // in flight together: the tail is a chain of dependent global round trips (~0.8 us each under load), so EB = 4
 // leaves one exposed latency per sub-tile instead of four.
+__device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
+}
+
 template <int EB, int CLS>
 __device__ __forceinline__ void patch_tail_fast(const ConvParams& p, const float* sW, int b, int mrow0, int nbase, int lane,
                                                 int M) {
@@ -279,7 +283,10 @@ __device__ __forceinline__ void patch_tail_fast(const ConvParams& p, const float
             const unsigned um = (unsigned)m;
             const unsigned o0 = ok ? um * (4u * (unsigned)p.aux0_ld) + n4 : BUF_OOB;
             if constexpr (CLS == 1) {
-                x[it].a0 = buf_load4(r_a0, o0, 0);
+                if (epi == EPI_LSTM_CELL)      // one hidden channel per quad: previous cell state is a scalar
+                    x[it].a0[0] = buf_load1(r_a0, ok ? um * (4u * (unsigned)p.aux0_ld) + (unsigned)n : BUF_OOB, 0);
+                else
+                    x[it].a0 = buf_load4(r_a0, o0, 0);
             } else if constexpr (CLS == 2) {
                 if (has_add) x[it].a2 = buf_load4(r_a2, ok ? um * ld_a2 + n4 : BUF_OOB, 0);
                 if (epi == EPI_GRU_ZR) {
@@ -419,6 +426,15 @@ __device__ __forceinline__ void patch_tail_fast(const ConvParams& p, const float
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = (n < p.split) ? sigmoidf_(v[e]) : tanhf(v[e]);
                     break;
+                case EPI_LSTM_CELL:
+                    if constexpr (CLS == 1) {
+                        // quad = in | remember | out | cell pre-activations of hidden channel n/4 (base_layers.py:117-132)
+                        to_out = false;
+                        const float c = sigmoidf_(v[1]) * a.a0[0] + sigmoidf_(v[0]) * tanhf(v[3]);
+                        buf_store1(r_out2, ok ? um * (4u * (unsigned)p.out2_ld) + (unsigned)n : BUF_OOB, c);
+                        buf_store1(r_out, ok ? um * (4u * (unsigned)p.out_ld) + (unsigned)n : BUF_OOB, sigmoidf_(v[2]) * tanhf(c));
+                    }
+                    break;
                 default: break;
             }
             buf_store4(r_out, (ok && to_out) ? um * (4u * (unsigned)p.out_ld) + n4 : BUF_OOB, o);
@@ -431,7 +447,7 @@ __device__ __forceinline__ void patch_tail(const ConvParams& p, const float* sW,
     if (p.epi_vec && nbase + 32 <= p.cout) {      // wave-uniform
         const int epi = p.epi;
         const bool one_aux = epi == EPI_SUB_FROM_AUX || epi == EPI_ADD_AUX_SHRINK || epi == EPI_RELU_ADD_AUX ||
-                             epi == EPI_RELU_ADD_AUX_RELU;
+                             epi == EPI_RELU_ADD_AUX_RELU || epi == EPI_LSTM_CELL;
         if (epi == EPI_LSTC) patch_tail_fast<1, 3>(p, sW, b, mrow0, nbase, lane, M);
         else if (p.addend || epi == EPI_GRU_ZR || epi == EPI_GRU_Q) patch_tail_fast<2, 2>(p, sW, b, mrow0, nbase, lane, M);
         else if (one_aux) patch_tail_fast<4, 1>(p, sW, b, mrow0, nbase, lane, M);
@@ -1604,6 +1620,8 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
             return hipErrorInvalidValue;
         if (p.epi == EPI_ADD_AUX_SHRINK && !p.lam) return hipErrorInvalidValue;
         if (p.addend && p.epi == EPI_LSTC) return hipErrorInvalidValue;      // they share a register slot
+        // the fused ConvLSTM cell exists only in the fast tail (gate-interleaved rows, whole 32-column patches)
+        if (p.epi == EPI_LSTM_CELL && (!p.epi_vec || p.addend || (p.cout % 32) != 0 || !p.aux0 || !p.out2)) return hipErrorInvalidValue;
     }
     const bool auto_tile = tile == 0;
     if (tile == 0 && smalln_ok(p)) tile = 7;
@@ -1694,8 +1712,11 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, float* __restr
                                    int KH, int KW, int cin_pad, int Ktot, int row0, int gather, int c_begin,
                                    int c_count, int dst_coff, int accum, const float* bn_w, const float* bn_b,
                                    const float* bn_mean, const float* bn_var, float bn_eps, const float* bias_src,
-                                   float* bias_dst) {
+                                   float* bias_dst, int interleave) {
     const long total = (long)Cout * c_count * KH * KW;
+    // interleave = G > 1: output channel o = g*(Cout/G) + j lands in row j*G + g (the G gates of hidden channel j
+    // become one quad of the conv tail -- EPI_LSTM_CELL)
+    const int per = interleave > 1 ? Cout / interleave : 1;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx < total) {
         const int kw = idx % KW;
@@ -1708,22 +1729,24 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, float* __restr
         if (bn_var) v *= bn_w[o] / sqrtf(bn_var[o] + bn_eps);
         const int tap = kh * KW + kw;
         const long k = gather ? ((long)tap * c_count + c) : ((long)tap * cin_pad + dst_coff + c);
-        float* d = dst + (long)(row0 + o) * Ktot + k;
+        const int orow = interleave > 1 ? (o % per) * interleave + o / per : o;
+        float* d = dst + (long)(row0 + orow) * Ktot + k;
         *d = accum ? (*d + v) : v;
     }
     if (idx < Cout && bias_dst) {
         const int o = (int)idx;
         float bv = bias_src ? bias_src[o] : 0.f;
         if (bn_var) bv = (bv - bn_mean[o]) * (bn_w[o] / sqrtf(bn_var[o] + bn_eps)) + bn_b[o];
-        bias_dst[row0 + o] = bv;
+        bias_dst[row0 + (interleave > 1 ? (o % per) * interleave + o / per : o)] = bv;
     }
 }
 
 hipError_t launch_pack_weight(const float* src, float* dst, int Cout, int Cin, int KH, int KW, int cin_pad,
                               int Ktot, int row0, int gather, int c_begin, int c_count, int dst_coff, int accum,
                               const float* bn_w, const float* bn_b, const float* bn_mean, const float* bn_var,
-                              float bn_eps, const float* bias_src, float* bias_dst, hipStream_t s) {
+                              float bn_eps, const float* bias_src, float* bias_dst, hipStream_t s, int interleave) {
     if (c_count <= 0) { c_begin = 0; c_count = Cin; }
+    if (interleave > 1 && (Cout % interleave) != 0) return hipErrorInvalidValue;
     const long total = (long)Cout * c_count * KH * KW;
     if (total <= 0 || c_begin < 0 || c_begin + c_count > Cin || dst_coff < 0) return hipErrorInvalidValue;
     if (gather) {
@@ -1735,7 +1758,7 @@ hipError_t launch_pack_weight(const float* src, float* dst, int Cout, int Cin, i
     const long blocks = (total + threads - 1) / threads;
     hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)blocks), dim3(threads), 0, s, src, dst, Cout, Cin, KH, KW,
                        cin_pad, Ktot, row0, gather, c_begin, c_count, dst_coff, accum, bn_w, bn_b, bn_mean, bn_var, bn_eps,
-                       bias_src, bias_dst);
+                       bias_src, bias_dst, interleave);
     return hipGetLastError();
 }
 

@@ -312,52 +312,6 @@ hipError_t launch_inorm_apply(const float* x, int ld, long bs, const float* stat
     return hipGetLastError();
 }
 
-// ---------------------------------------------------------------------------
-// ConvLSTM cell (e2v/base_layers.py:117-132): gates arrive activated from the conv epilogue
-// in chunk order  in | remember | out | cell.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void lstm_cell_kernel(const float* __restrict__ g, int g_ld, long g_bs,
-                                                        const float* __restrict__ c_prev, int cp_ld, long cp_bs,
-                                                        float* __restrict__ h_out, int h_ld, long h_bs,
-                                                        float* __restrict__ c_out, int c_ld, long c_bs, int B, int HW,
-                                                        int Ch) {
-    const int cq = Ch / 4;
-    const long total = (long)B * HW * cq;
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= total) return;
-    const int c0 = (int)(gid % cq) * 4;
-    const long pix = gid / cq;
-    const int p = (int)(pix % HW);
-    const int b = (int)(pix / HW);
-    const float* gp = g + (long)b * g_bs + (long)p * g_ld + c0;
-    const f32x4 ig = *reinterpret_cast<const f32x4*>(gp);
-    const f32x4 fg = *reinterpret_cast<const f32x4*>(gp + Ch);
-    const f32x4 og = *reinterpret_cast<const f32x4*>(gp + 2 * Ch);
-    const f32x4 cg = *reinterpret_cast<const f32x4*>(gp + 3 * Ch);
-    f32x4 cp = {0.f, 0.f, 0.f, 0.f};
-    if (c_prev) cp = *reinterpret_cast<const f32x4*>(c_prev + (long)b * cp_bs + (long)p * cp_ld + c0);
-    f32x4 c, h;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        c[e] = fg[e] * cp[e] + ig[e] * cg[e];
-        h[e] = og[e] * tanhf(c[e]);
-    }
-    *reinterpret_cast<f32x4*>(c_out + (long)b * c_bs + (long)p * c_ld + c0) = c;
-    *reinterpret_cast<f32x4*>(h_out + (long)b * h_bs + (long)p * h_ld + c0) = h;
-}
-
-hipError_t launch_lstm_cell(const float* g, int g_ld, long g_bs, const float* c_prev, int cp_ld, long cp_bs,
-                            float* h_out, int h_ld, long h_bs, float* c_out, int c_ld, long c_bs, int B, int HW, int Ch,
-                            hipStream_t s) {
-    if (!g || !h_out || !c_out || (Ch % 4) != 0 || (g_ld % 4) != 0 || (h_ld % 4) != 0 || (c_ld % 4) != 0 ||
-        (g_bs % 4) != 0 || (h_bs % 4) != 0 || (c_bs % 4) != 0 || g_ld < 4 * Ch)
-        return hipErrorInvalidValue;
-    if (c_prev && ((cp_ld % 4) != 0 || (cp_bs % 4) != 0)) return hipErrorInvalidValue;
-    const long total = (long)B * HW * (Ch / 4);
-    hipLaunchKernelGGL(lstm_cell_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g, g_ld, g_bs, c_prev,
-                       cp_ld, cp_bs, h_out, h_ld, h_bs, c_out, c_ld, c_bs, B, HW, Ch);
-    return hipGetLastError();
-}
 
 // ---------------------------------------------------------------------------
 // correlation pyramid: F.avg_pool2d(corr, 2, stride=2) over the (h2,w2) plane of every

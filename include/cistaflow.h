@@ -80,7 +80,8 @@ int cf_warp(cf_handle* h, const float* img, const float* flow, float* out, int B
 
 /* a3  CistaLSTCNet.forward (e2v/e2v_model.py:49-98).
  *   ev NCHW [B][bins][H][W], img NCHW [B][1][H][W];
- *   states NHWC at (H/2,W/2): c,z 2*base channels; h,cc base channels; *_prev may be NULL (zeros). */
+ *   states NHWC at (H/2,W/2): c,z 2*base channels; h,cc base channels; *_prev may be NULL (zeros).
+ *   The *_out states must not alias the *_prev ones (the reference returns fresh tensors each frame too). */
 int cf_cista_forward(cf_handle* h, const float* ev, const float* img, const float* c_prev, const float* z_prev,
                      const float* h_prev, const float* cc_prev, float* I_out, float* c_out, float* z_out,
                      float* h_out, float* cc_out, void* stream);
