@@ -284,3 +284,41 @@ def test_eiflow_f16x3_precision_mode(gpu):
             worst = max(worst, max(errs))
             prev = I.clone()
     assert worst < 3e-4, worst
+
+
+@pytest.mark.parametrize("H,W,B", [(180, 240, 8), (480, 640, 2)])
+def test_full_size_batch_properties(gpu, H, W, B):
+    """BASELINE configs[1] / configs[3] geometry (full sizes, where the oracle is too slow for the whole batch):
+    size-independent properties of the step.  Sequences are independent, so (a) identical inputs in different
+    batch slots give bit-identical outputs (every kernel indexes its image correctly at full size), (b) a slot's
+    result does not depend on what the other slots hold, (c) re-running is deterministic, and (d) one slot of
+    one frame agrees with the CPU oracle."""
+    from oracle import cista_oracle as orc
+    m = build_eiflow(H, W, 4242, gpu)
+    ev0 = wu.synth_events(1, 5, H, W, 9100)
+    ev1 = wu.synth_events(1, 5, H, W, 9101)
+    evA = torch.cat([ev0] * B, 0).to(gpu)                    # all slots equal
+    evB = torch.cat([ev0] + [ev1] * (B - 1), 0).to(gpu)      # slot 0 equal, the rest different
+    prev = torch.zeros(B, 1, H, W, device=gpu)
+    with torch.no_grad():
+        IA1, bfA1, stA1 = m({"event_voxel": evA, "rec_img0": prev}, None, {})
+        IA2, bfA2, stA2 = m({"event_voxel": evA, "rec_img0": IA1.clone()}, stA1, {})
+        IB1, bfB1, stB1 = m({"event_voxel": evB, "rec_img0": prev}, None, {})
+        IA1r, bfA1r, _ = m({"event_voxel": evA, "rec_img0": prev}, None, {})
+    torch.cuda.synchronize()
+    assert torch.isfinite(IA2).all()
+    for k in range(1, B):                                    # (a), on both the cold and the recurrent frame
+        assert torch.equal(IA1[k], IA1[0]) and torch.equal(IA2[k], IA2[0]), k
+        assert torch.equal(bfA2["flow_final"][k], bfA2["flow_final"][0]), k
+        assert torch.equal(stA2[1][k], stA2[1][0]) and torch.equal(stA2[2][0][k], stA2[2][0][0]), k
+    assert torch.equal(IB1[0], IA1[0]) and torch.equal(bfB1["flow_final"][0], bfA1["flow_final"][0])   # (b)
+    assert not torch.equal(IB1[1], IA1[1])
+    assert torch.equal(IA1r, IA1) and torch.equal(bfA1r["flow_final"], bfA1["flow_final"])                 # (c)
+    # (d) slot 0, two frames, against the oracle at B=1
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        I1, bf1, st1 = orc.eiflow_step(sd, {"event_voxel": ev0, "rec_img0": torch.zeros(1, 1, H, W)}, None)
+        I2, bf2, st2 = orc.eiflow_step(sd, {"event_voxel": ev0, "rec_img0": I1.clone()}, st1)
+    assert gu.rel_err(IA1[:1].cpu(), I1) < TOL and gu.rel_err(IA2[:1].cpu(), I2) < TOL
+    assert gu.rel_err(bfA2["flow_final"][:1].cpu(), bf2["flow_final"]) < TOL
+    assert gu.rel_err(stA2[1][:1].cpu(), st2[1]) < TOL
