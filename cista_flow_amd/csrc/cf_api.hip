@@ -1407,6 +1407,13 @@ extern "C" int cf_op_corr_lookup(const float* fmap1, const float* fmap2, const f
 }
 
 // f-1: events -> normalised voxel grids (the step right before the hot path; utils/event_process.py)
+// f-2 (output stage): uint8 quantisation of reconstructed frames on the device, so that only H*W bytes per frame
+// cross PCIe instead of 4*H*W.  No handle needed: stateless.
+extern "C" int cf_quantize_u8(const float* img, unsigned char* out, long long n, void* stream) {
+    if (!img || !out || n <= 0) return CF_ERR_ARG;
+    return launch_quantize_u8(img, out, (long)n, static_cast<hipStream_t>(stream)) == hipSuccess ? CF_OK : CF_ERR_HIP;
+}
+
 extern "C" int cf_events_to_voxel(const double* events, const int64_t* offsets, int B, int bins, int H, int W, float* voxel,
                                   double* stats_scratch, int normalize, void* stream) {
     static_assert(sizeof(long) == sizeof(int64_t), "LP64");

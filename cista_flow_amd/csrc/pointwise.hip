@@ -750,4 +750,29 @@ hipError_t launch_nhwc_to_nchw(const float* src, int src_ld, float* dst, int B, 
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// f-2 output stage: np.uint8(pred * 255.)  (test_with_flow.py:174) -- fp32 product, truncation toward zero
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void quantize_u8_kernel(const float* __restrict__ x, unsigned char* __restrict__ out, long n) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n && ((reinterpret_cast<uintptr_t>(x + i) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out + i) & 3) == 0)) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
+        uchar4 o;
+        o.x = (unsigned char)(v[0] * 255.f);
+        o.y = (unsigned char)(v[1] * 255.f);
+        o.z = (unsigned char)(v[2] * 255.f);
+        o.w = (unsigned char)(v[3] * 255.f);
+        *reinterpret_cast<uchar4*>(out + i) = o;
+    } else {
+        for (long k = i; k < n && k < i + 4; ++k) out[k] = (unsigned char)(x[k] * 255.f);
+    }
+}
+
+hipError_t launch_quantize_u8(const float* x, unsigned char* out, long n, hipStream_t s) {
+    if (!x || !out || n <= 0) return hipErrorInvalidValue;
+    const long threads = (n + 3) / 4;
+    hipLaunchKernelGGL(quantize_u8_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, x, out, n);
+    return hipGetLastError();
+}
+
 }  // namespace cf

@@ -27,3 +27,18 @@ class ImagePadder(object):
 
     def unpad(self, image):
         return image[..., self.pad_height:, self.pad_width:]
+
+
+def to_uint8(pred):
+    """`np.uint8(pred * 255.)` of the drivers' output stage (test_with_flow.py:174) on the GPU: pred float32 CUDA
+    tensor in [0, 1] -> uint8 tensor of the same shape (D2H then moves 1 byte per pixel instead of 4)."""
+    import torch
+    from .. import lib as _lib
+    L = _lib.load()
+    _lib.check_f32_cuda(pred, "pred", tuple(pred.shape))
+    x = pred.contiguous()
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    rc = L.cf_quantize_u8(_lib.ptr(x), out.data_ptr(), x.numel(), _lib.current_stream_ptr())
+    if rc != 0:
+        raise RuntimeError("cf_quantize_u8 failed (%d)" % rc)
+    return out

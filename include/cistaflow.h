@@ -109,6 +109,11 @@ int cf_step(cf_handle* h, const float* in0, const float* in1, const float* rec_i
 int cf_events_to_voxel(const double* events, const int64_t* offsets, int B, int bins, int H, int W, float* voxel,
                        double* stats_scratch, int normalize, void* stream);
 
+/* f-2  output stage, `np.uint8(pred_image * 255.)` (test_with_flow.py:174): fp32 product, truncation toward zero,
+ * on the device (img: n floats in [0,1], out: n bytes).  Stateless, asynchronous on `stream`.  The PNG encoder and the
+ * flow -> HSV colour coding (utils/data_io.py:9-29, defined by cv2.cartToPolar / cvtColor) stay on the host. */
+int cf_quantize_u8(const float* img, unsigned char* out, long long n, void* stream);
+
 /* measurement: when enabled, every convolution launch of the fused paths is bracketed by HIP events on
  * the launch stream and the library's side streams are folded into the caller's stream (kernels run one at
  * a time, so a duration is that kernel alone on the chip -- what a roofline fraction needs).  cf_profile_read synchronises them and returns, for conv tile kind t = 1..6

@@ -387,3 +387,19 @@ def test_conv_f16_split_modes(gpu, case, prec, tol):
     torch.cuda.synchronize()
     err = ((nchw(out.cpu()) - ref).abs().max() / ref.abs().max()).item()
     assert err < tol, err
+
+
+def test_quantize_u8_matches_numpy(gpu):
+    """f-2: np.uint8(pred * 255.) (test_with_flow.py:174) -- bit-exact, including the k/255 boundaries, 0 and 1."""
+    import numpy as np
+    from cista_flow_amd.utils.image_process import to_uint8
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(3, 1, 37, 53, generator=g)
+    k = torch.arange(256, dtype=torch.float32)
+    edge = torch.cat([k / 255.0, torch.nextafter(k / 255.0, torch.tensor(2.0)).clamp(max=1.0),
+                      torch.nextafter(k / 255.0, torch.tensor(-1.0)).clamp(min=0.0), torch.tensor([0.0, 1.0, 0.5, 0.999999])])
+    for t in (x, edge.reshape(1, 1, 1, -1), torch.sigmoid(torch.randn(2, 1, 180, 240, generator=g) * 6)):
+        want = np.uint8(t.numpy() * 255.)
+        got = to_uint8(t.to(gpu)).cpu().numpy()
+        assert got.dtype == np.uint8 and got.shape == want.shape
+        assert (got == want).all()
