@@ -322,3 +322,39 @@ def test_full_size_batch_properties(gpu, H, W, B):
     assert gu.rel_err(IA1[:1].cpu(), I1) < TOL and gu.rel_err(IA2[:1].cpu(), I2) < TOL
     assert gu.rel_err(bfA2["flow_final"][:1].cpu(), bf2["flow_final"]) < TOL
     assert gu.rel_err(stA2[1][:1].cpu(), st2[1]) < TOL
+
+
+def _idnet_sequence_errors(gpu, name, precision):
+    from cista_flow_amd.e2v.e2v_model import IDCistaNet
+    g = gu.load(name)
+    H, W, B, frames, seed = [int(v) for v in g["meta"]]
+    m = IDCistaNet(args_for(H, W)).eval()
+    m.precision = precision
+    wu.fill_module(m, seed)
+    m = m.to(gpu)
+    states, prev, flow_init = None, torch.zeros(B, 1, H, W, device=gpu), None
+    worst = {}
+    with torch.no_grad():
+        for t in range(frames):
+            ev = torch.from_numpy(g["ev_%d" % t]).to(gpu)
+            I, bf, states = m({"event_voxel": ev, "rec_img0": prev}, states, flow_init, {})
+            flow_init = bf["next_flow"]
+            errs = {"flow": gu.rel_err(bf["flow_final"].cpu(), g["flow_%d" % t]), "I": gu.rel_err(I.cpu(), g["I_%d" % t]),
+                    "z": gu.rel_err(gu.sub(states[1].cpu()), g["z_%d" % t]), "c": gu.rel_err(gu.sub(states[0].cpu()), g["c_%d" % t]),
+                    "h": gu.rel_err(gu.sub(states[2][0].cpu()), g["h_%d" % t])}
+            for k, v in errs.items():
+                worst[k] = max(worst.get(k, 0.0), v)
+            prev = I.clone()
+    return worst
+
+
+def test_idnet_f16_precision_mode(gpu):
+    """BASELINE configs[4] ("cista-idnet 346x260 batch=16, fp16 with MFMA"): plain-f16 operands, fp32 accumulate and
+    fp32 tensors, against the fp32 reference golden.  One f16 rounding of each operand is ~5e-4 relative, so this
+    mode cannot meet the 1e-3 fp32 bar by construction; the tolerance asserted here is 1e-2 of tensor scale over a
+    recurrent 3-frame sequence (observed: <= 3e-3; values are printed by -s).  f16x3 on the same sequence stays under 3e-4."""
+    w16 = _idnet_sequence_errors(gpu, "idnet_260x346.npz", "f16")
+    w3 = _idnet_sequence_errors(gpu, "idnet_260x346.npz", "f16x3")
+    print("idnet 260x346 worst rel err  f16:", w16, " f16x3:", w3)
+    assert max(w3.values()) < 3e-4, w3
+    assert max(w16.values()) < 1e-2, w16
