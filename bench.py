@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--width", type=int, default=240)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=3)
+    ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--no-alt", action="store_true", help="skip the extra f16x3-precision timing leg")
     ap.add_argument("--model", default="eiflow", choices=["eiflow", "eraft", "idnet"],
                     help="flow network (the BASELINE metric is eiflow; the others are extra workloads)")
