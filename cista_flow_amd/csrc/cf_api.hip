@@ -121,15 +121,24 @@ struct cf_handle {
     bool ph_pending = false;
     double ph_ms[3] = {0, 0, 0};
     long ph_n = 0;
-    void phase_mark(int i, hipStream_t st) { if (phases) (void)hipEventRecord(ph_ev[i], st); }
+    bool ph_rec[4] = {false, false, false, false};
+    void phase_mark(int i, hipStream_t st) {
+        if (phases && hipEventRecord(ph_ev[i], st) == hipSuccess) ph_rec[i] = true;
+    }
     void phase_collect() {
         if (!phases || !ph_pending) return;
         ph_pending = false;
-        if (hipEventSynchronize(ph_ev[3]) != hipSuccess) return;
-        for (int i = 0; i < 3; ++i) {
+        if (hipEventSynchronize(ph_ev[3]) != hipSuccess) { (void)hipGetLastError(); return; }
+        // IDNet has no encoder / iteration boundary (mark 1): its whole flow network is booked under phase 0
+        int prev = 0;
+        for (int i = 1; i < 4; ++i) {
+            if (!ph_rec[i]) continue;
             float t = 0.f;
-            if (hipEventElapsedTime(&t, ph_ev[i], ph_ev[i + 1]) == hipSuccess) ph_ms[i] += t;
+            if (hipEventElapsedTime(&t, ph_ev[prev], ph_ev[i]) == hipSuccess) ph_ms[prev == 0 && i == 2 ? 0 : i - 1] += t;
+            else (void)hipGetLastError();
+            prev = i;
         }
+        for (int i = 0; i < 4; ++i) ph_rec[i] = false;
         ++ph_n;
     }
     std::vector<ProfRec> prof_recs;

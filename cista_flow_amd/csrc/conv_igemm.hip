@@ -1545,6 +1545,9 @@ const char* conv_tile_name(int tile) {
         case 25: return "conv_dma_kernel<128,128,2,2,1,16>";
         case 26: return "conv_dma_kernel<128,64,2,2,1,16>";
         case 27: return "conv_dma_kernel<128,64,2,2,1,32>";
+        case 28: return "conv_dma_kernel<64,128,2,2,1,16>";
+        case 29: return "conv_dma_kernel<128,96,4,1,1,16>";
+        case 30: return "conv_dma_kernel<128,32,4,1,1,16>";
         default: return "?";
     }
 }
@@ -1656,6 +1659,7 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
     }
     if (tile == 0) return hipErrorInvalidValue;
     if (auto_tile) {
+        const long wgs128x128 = (((long)p.Ho * p.Wo + 127) / 128) * ((p.cout + 127) / 128) * batch;
         // wide stages (32 k-columns per wave between barriers) measured 3-8 % faster wherever the channel
         // segments allow them (tools/conv_bench.py, MI355X)
         if (tile == 9 && stage_ok(p, 64)) tile = 10;
@@ -1666,7 +1670,13 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
             else if (tile == 8 && stage_ok(p, 64)) tile = 22;
             else if (tile == 4 || tile == 12) tile = 23;
             else if (tile == 2) tile = 26;
-            else if (tile == 1) tile = (p.cout >= 256 && p.cout % 64 == 0) ? 26 : 23;   // in-model sweep (tools/tile_sweep.sh)
+            else if (tile == 5) tile = 28;
+            else if (tile == 3) tile = 29;
+            else if (tile == 6) tile = 30;
+            else if (tile == 1)
+                // 128x128 once there are >= 3 full rounds of it (config 4 / 5 sizes: 125-135 TFLOP/s); with fewer
+                // workgroups the smaller tiles overlap prologue / tail better (180x240 B=8: tools/tile_sweep.sh)
+                tile = wgs128x128 >= 2304 ? 25 : ((p.cout >= 256 && p.cout % 64 == 0) ? 26 : 23);
         }
     }
     if (tile_used) *tile_used = tile;
@@ -1701,6 +1711,9 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
         case 25: return launch_dma<128, 128, 2, 2, 1, 16>(p, batch, s);
         case 26: return launch_dma<128, 64, 2, 2, 1, 16>(p, batch, s);
         case 27: return launch_dma<128, 64, 2, 2, 1, 32>(p, batch, s);
+        case 28: return launch_dma<64, 128, 2, 2, 1, 16>(p, batch, s);
+        case 29: return launch_dma<128, 96, 4, 1, 1, 16>(p, batch, s);
+        case 30: return launch_dma<128, 32, 4, 1, 1, 16>(p, batch, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -107,6 +107,11 @@ CONV_CASES = [
     (336, 256, 1, 1, 1, 0, 0, 0, 25),
     (128, 64, 3, 3, 1, 1, 1, 1, 26),
     (64, 128, 3, 3, 1, 1, 1, 0, 27),
+    (96, 256, 3, 3, 1, 1, 1, 0, 28),
+    (256, 576, 1, 1, 1, 0, 0, 0, 29),
+    (64, 96, 3, 3, 1, 1, 1, 1, 29),
+    (32, 32, 3, 3, 1, 1, 1, 0, 30),
+    (64, 32, 3, 3, 2, 1, 1, 1, 30),
 ]
 
 

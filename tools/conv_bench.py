@@ -31,6 +31,13 @@ SHAPES = [
     ("out_gates 256->128 3x3 @90x120", 8, 256, 90, 120, 128, 3, 3, 1, 1, 1, 1),
     ("Gates     128->256 3x3 @90x120", 8, 128, 90, 120, 256, 3, 3, 1, 1, 1, 1),
     ("W0         64->64  3x3/2 @180x240", 8, 64, 180, 240, 64, 3, 3, 2, 1, 1, 1),
+    # the same CISTA layers at cista-idnet 260x346 B=16 (config 5) and cista-eiflow 480x640 B=4 (config 4)
+    ("big.gates 192->256 3x3 @130x173 B16", 16, 192, 130, 173, 256, 3, 3, 1, 1, 1, 1),
+    ("big.out_g 256->128 3x3 @130x173 B16", 16, 256, 130, 173, 128, 3, 3, 1, 1, 1, 1),
+    ("big.P      64->128 3x3 @130x173 B16", 16, 64, 130, 173, 128, 3, 3, 1, 1, 1, 1),
+    ("big.D     128->64  3x3 @130x173 B16", 16, 128, 130, 173, 64, 3, 3, 1, 1, 1, 1),
+    ("hs.gates  192->256 3x3 @240x320 B4", 4, 192, 240, 320, 256, 3, 3, 1, 1, 1, 1),
+    ("hs.P       64->128 3x3 @240x320 B4", 4, 64, 240, 320, 128, 3, 3, 1, 1, 1, 1),
 ]
 
 
