@@ -102,6 +102,7 @@ struct cf_handle {
     float *coords1 = nullptr, *corrfeat = nullptr, *c1buf = nullptr, *mcat = nullptr, *e1buf = nullptr, *f1buf = nullptr,
           *motion = nullptr, *zbuf = nullptr, *rh = nullptr, *fh = nullptr;
     float* gpre[2] = {nullptr, nullptr};
+    float* mpre = nullptr;             // menc.pre output [B][N][128]
     float *mask1 = nullptr, *maskbuf = nullptr;   // ERAFT / IDNet mask head
     // IDNet
     float *idDeblur = nullptr, *idA = nullptr, *idB = nullptr, *idC = nullptr, *idD = nullptr, *idF = nullptr,
@@ -263,6 +264,7 @@ static void setup_buffers(cf_handle* H_) {
         s.fh = a.f(B * N * 256);
         s.gpre[0] = a.f(B * N * 384);
         s.gpre[1] = a.f(B * N * 384);
+        s.mpre = a.f(B * N * 128);
         if (s.cfg.mode == CF_MODE_ERAFT) {
             s.mask1 = a.f(B * N * 256);
             s.maskbuf = a.f(B * N * 576);
@@ -526,7 +528,15 @@ extern "C" int cf_finalize_weights(cf_handle* h, void* stream) {
         }
         if ((rc = F("convf1", e + "convf1", true))) return rc;
         if ((rc = F("convf2", e + "convf2", false))) return rc;
-        if ((rc = F("menc.conv", e + "conv", false))) return rc;
+        if (eraft) {
+            if ((rc = F("menc.conv", e + "conv", false))) return rc;
+        } else {
+            // BasicMotionEncoder.conv over cat(cor 192 | ema 64 | flo 64) is linear before its ReLU, and the emap branch
+            // is iteration-invariant (with_event_updater.py:105-106): its slice becomes menc.pre, evaluated once per
+            // frame (bias included); the per-iteration matrix keeps cor | flo only
+            if ((rc = pack_conv(h, "menc.conv", f + e + "conv", false, 0, 0, "", st, {{0, 192, 0}, {256, 64, 192}}, 256, false))) return rc;
+            if ((rc = pack_conv(h, "menc.pre", f + e + "conv", false, 0, 0, "", st, {{192, 64, 0}}, 64, true))) return rc;
+        }
         const std::string g = f + "update_block.gru.";
         // SepConvGRU (with_event_updater.py:52-67), hx = cat(h, inp, motion).  Each conv is linear, so its
         // `inp` slice (channels 128..255, iteration-invariant) is split off into gru.preN (z | r | q stacked,
@@ -1005,6 +1015,8 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
         CF_HIP(h, run_conv(h, b, B, st));
         ConvParams c = nhwc_conv(h->conv["fusion.conv2"], {{h->emap, 256, 256, N * 256}}, h8, w8, h8, w8, 1, 0, 0, 0, h->fcat + 192, 384, N * 384, EPI_RELU);
         CF_HIP(h, run_conv(h, c, B, st));
+        ConvParams mp = nhwc_conv(h->conv["menc.pre"], {{h->mcat + 192, 64, 320, N * 320}}, h8, w8, h8, w8, 1, 1, 1, 0, h->mpre, 128, N * 128, EPI_NONE);
+        CF_HIP(h, run_conv(h, mp, B, st));
     }
     CF_HIP(h, hipStreamWaitEvent(st, h->ev_join[0], 0));
     CF_HIP(h, hipStreamWaitEvent(st, h->ev_join[1], 0));
@@ -1059,7 +1071,13 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
         ConvParams c2 = nhwc_conv(h->conv["convc2"], {{h->c1buf, 256, 256, N * 256}}, h8, w8, h8, w8, 1, 1, 1, 0, h->mcat, MC, N * MC, EPI_RELU);
         CF_HIP(h, run_conv(h, c2, B, st));
         CF_HIP(h, hipStreamWaitEvent(st, h->ev_join[0], 0));
-        ConvParams mc = nhwc_conv(h->conv["menc.conv"], {{h->mcat, MC, MC, N * MC}}, h8, w8, h8, w8, 1, 1, 1, 0, h->motion, 128, N * 128, EPI_RELU);
+        ConvParams mc = eraft ? nhwc_conv(h->conv["menc.conv"], {{h->mcat, MC, MC, N * MC}}, h8, w8, h8, w8, 1, 1, 1, 0, h->motion, 128, N * 128, EPI_RELU)
+                              : nhwc_conv(h->conv["menc.conv"], {{h->mcat, 192, MC, N * MC}, {h->mcat + FLO, 64, MC, N * MC}}, h8, w8, h8, w8, 1, 1, 1, 0,
+                                          h->motion, 128, N * 128, EPI_RELU);
+        if (!eraft) {       // + the emap slice evaluated once per frame (menc.pre)
+            mc.bias = nullptr;
+            mc.addend = h->mpre; mc.addend_ld = 128; mc.addend_bs = N * 128;
+        }
         CF_HIP(h, run_conv(h, mc, B, st));
         // SepConvGRU  with_event_updater.py:52-67 ; hx = cat(h, inp, motion), inp part precomputed (gpre)
         for (int pass = 0; pass < 2; ++pass) {
