@@ -209,21 +209,40 @@ __global__ __launch_bounds__(256) void inorm_partial_kernel(const float* __restr
     }
 }
 
-// one workgroup = (image, 16 channels): 16 thread rows walk the chunks in parallel (independent 16-byte loads),
-// then thread row 0 folds the 16 row sums in a fixed order -- deterministic, ~2-3 us instead of a serial chunk walk
+// one workgroup = (image, 4 channels): 64 thread rows walk the chunks in parallel with all of a thread's 16-byte
+// loads in flight at once (the partials were just written by other XCDs, so every load is a fabric round trip and
+// the fold is latency-bound); thread row 0 then adds the 64 row sums in a fixed order -- deterministic
 __global__ __launch_bounds__(256) void inorm_final_kernel(const double* __restrict__ partial, int nchunk, int C, int HW,
                                                           float eps, float* __restrict__ stats) {
-    __shared__ double sh[16][16][2];
+    __shared__ double sh[64][4][2];
     const int b = blockIdx.y;
-    const int cl = threadIdx.x & 15, k = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    const int cl = threadIdx.x & 3, k = threadIdx.x >> 2;
+    const int c = blockIdx.x * 4 + cl;
     double s = 0.0, ss = 0.0;
     if (c < C) {
         const double* src = partial + ((long)b * nchunk * C + c) * 2;
-        for (int i = k; i < nchunk; i += 16) {
-            const double2 v = *reinterpret_cast<const double2*>(src + (long)i * C * 2);
-            s += v.x;
-            ss += v.y;
+        int i = k;
+        for (; i + 7 * 64 < nchunk; i += 8 * 64) {
+            double2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const double2*>(src + (long)(i + u * 64) * C * 2);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                s += v[u].x;
+                ss += v[u].y;
+            }
+        }
+        double2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            v[u].x = 0.0;
+            v[u].y = 0.0;
+            if (i + u * 64 < nchunk) v[u] = *reinterpret_cast<const double2*>(src + (long)(i + u * 64) * C * 2);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            s += v[u].x;
+            ss += v[u].y;
         }
     }
     sh[k][cl][0] = s;
@@ -231,8 +250,8 @@ __global__ __launch_bounds__(256) void inorm_final_kernel(const double* __restri
     __syncthreads();
     if (k == 0 && c < C) {
         double a = 0.0, aa = 0.0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
+#pragma unroll 8
+        for (int r = 0; r < 64; ++r) {
             a += sh[r][cl][0];
             aa += sh[r][cl][1];
         }
@@ -248,7 +267,7 @@ __global__ __launch_bounds__(256) void inorm_final_kernel(const double* __restri
 hipError_t launch_inorm_final(const double* partial, int nchunk, int B, int HW, int C, float eps, float* stats,
                               hipStream_t s) {
     if (!partial || !stats || nchunk <= 0 || B <= 0 || HW <= 0 || C <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(inorm_final_kernel, dim3((C + 15) / 16, B), dim3(256), 0, s, partial, nchunk, C, HW, eps, stats);
+    hipLaunchKernelGGL(inorm_final_kernel, dim3((C + 3) / 4, B), dim3(256), 0, s, partial, nchunk, C, HW, eps, stats);
     return hipGetLastError();
 }
 
