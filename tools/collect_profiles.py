@@ -30,6 +30,8 @@ def main():
                                                        float(r["AverageNs"]) / 1e3, r["Percentage"]))
     shutil.copy(os.path.join(src, "layers.txt"), os.path.join(dst, tag + "_conv_layers_hip_events.txt"))
     shutil.copy(os.path.join(src, "hbm_traffic.json"), os.path.join(dst, "hbm_traffic.json"))
+    if os.path.exists(os.path.join(src, "mfma_busy.txt")):
+        shutil.copy(os.path.join(src, "mfma_busy.txt"), os.path.join(dst, tag + "_mfma_busy.txt"))
     line = open(os.path.join(src, "bench.log")).read().strip().splitlines()[-1]
     open(os.path.join(dst, tag + "_bench_line.json"), "w").write(line + "\n")
     print("profiles/ updated from", src)
