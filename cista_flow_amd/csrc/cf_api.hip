@@ -94,8 +94,8 @@ struct cf_handle {
         double* partial = nullptr;
     } enc[3];
     // library-owned side streams, forked from / joined to the caller's stream with events
-    hipStream_t aux[2] = {nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    hipStream_t aux[3] = {nullptr, nullptr, nullptr};   // library-owned side streams
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     float *fmap1 = nullptr, *emap = nullptr, *fcat = nullptr, *pfmap2 = nullptr, *net = nullptr, *inp = nullptr;
     float* corr[4] = {nullptr, nullptr, nullptr, nullptr};
     int clh[4] = {0, 0, 0, 0}, clw[4] = {0, 0, 0, 0};
@@ -115,6 +115,8 @@ struct cf_handle {
     std::string prof_report;
     bool prof = false;
     bool serial = false;   // measurement mode: no side-stream concurrency
+    // batch window applied by run_conv (images [win_b0, win_b0 + win_n) of every tensor); win_n == 0: whole batch
+    int win_b0 = 0, win_n = 0;
     // CF_PHASES=1 (tuning aid): HIP events on the caller's stream at the phase boundaries of cf_step, averaged
     // and printed to stderr by cf_destroy
     bool phases = false;
@@ -194,6 +196,18 @@ static hipError_t run_conv(cf_handle* h, const ConvParams& p_in, int batch, hipS
     ConvParams p = p_in;
     p.prec = h ? h->cfg.precision : 0;
     if (tile == 0) tile = tile_override(p.tag ? p.tag : (h ? h->tag : nullptr));
+    if (h && h->win_n > 0) {
+        const long b0 = h->win_b0;
+        batch = h->win_n;
+        for (int i = 0; i < p.nseg; ++i) p.in[i] += b0 * p.seg_bs[i];
+        p.out += b0 * p.out_bs;
+        if (p.out2) p.out2 += b0 * p.out2_bs;
+        if (p.aux0) p.aux0 += b0 * p.aux0_bs;
+        if (p.aux1) p.aux1 += b0 * p.aux1_bs;
+        if (p.aux2) p.aux2 += b0 * p.aux2_bs;
+        if (p.aux3) p.aux3 += b0 * p.aux3_bs;
+        if (p.addend) p.addend += b0 * p.addend_bs;
+    }
     if (!h || !h->prof) return launch_conv(p, batch, st, tile);
     cf_handle::ProfRec r;
     r.a = h->prof_event();
@@ -673,7 +687,7 @@ extern "C" int cf_create(cf_handle** out, const cf_config* cfg) {
         h->phases = atoi(e) != 0;
         for (int i = 0; h->phases && i < 4; ++i) ok = ok && hipEventCreate(&h->ph_ev[i]) == hipSuccess;
     }
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 3; ++i) {
         ok = ok && hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming) == hipSuccess;
     }
@@ -697,7 +711,7 @@ extern "C" void cf_destroy(cf_handle* h) {
     (void)hipSetDevice(h->cfg.device);
     for (void* p : h->owned) (void)hipFree(p);
     if (h->arena_mem) (void)hipFree(h->arena_mem);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 3; ++i) {
         if (h->aux[i]) { (void)hipStreamSynchronize(h->aux[i]); (void)hipStreamDestroy(h->aux[i]); }
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
     }
@@ -780,9 +794,53 @@ extern "C" int cf_warp(cf_handle* h, const float* img, const float* flow, float*
 // ---------------------------------------------------------------------------------------------
 // a3 CISTA-LSTC
 // ---------------------------------------------------------------------------------------------
+static int cista_chain(cf_handle* h, const float* ev, const float* img, const float* c_prev, const float* z_prev,
+                       const float* h_prev, const float* cc_prev, float* I_out, float* c_out, float* z_out,
+                       float* h_out, float* cc_out, hipStream_t st);
+
+// CF_CISTA_CHAINS = 1 | 2 | 4 forces the number of part-batch chains; default (0): chosen per geometry
+static int cista_chains_env() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("CF_CISTA_CHAINS");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
 static int cista_forward(cf_handle* h, const float* ev, const float* img, const float* c_prev, const float* z_prev,
                          const float* h_prev, const float* cc_prev, float* I_out, float* c_out, float* z_out,
                          float* h_out, float* cc_out, hipStream_t st) {
+    // Sequences are independent: the CISTA convs can run as part-batch chains on several streams, so that one
+    // chain's prologues / tails overlap the others' main loops.  Measured (tools/chains_sweep.sh): two chains gain
+    // 1.5-3.6 % at 180x240 for B = 2..16, nothing at 480x640 B=4 and lose 2.6 % at 260x346 B=16 (each launch then
+    // drops out of the many-rounds regime the 128x128 tile needs); four chains always lose.
+    int nch = cista_chains_env();
+    if (nch == 0) nch = ((h->B % 2) == 0 && (long)h->h * h->w * (h->B / 2) <= 100000) ? 2 : 1;
+    if ((nch != 2 && nch != 4) || h->serial || (h->B % nch) != 0)
+        return cista_chain(h, ev, img, c_prev, z_prev, h_prev, cc_prev, I_out, c_out, z_out, h_out, cc_out, st);
+    hipStream_t cs[4] = {st, h->aux[0], h->aux[1], h->aux[2]};
+    CF_HIP(h, hipEventRecord(h->ev_fork, st));
+    for (int g = 1; g < nch; ++g) CF_HIP(h, hipStreamWaitEvent(cs[g], h->ev_fork, 0));
+    int rc = CF_OK;
+    for (int g = 0; g < nch && rc == CF_OK; ++g) {
+        h->win_b0 = g * (h->B / nch);
+        h->win_n = h->B / nch;
+        rc = cista_chain(h, ev, img, c_prev, z_prev, h_prev, cc_prev, I_out, c_out, z_out, h_out, cc_out, cs[g]);
+    }
+    h->win_b0 = 0;
+    h->win_n = 0;
+    if (rc != CF_OK) return rc;
+    for (int g = 1; g < nch; ++g) {
+        CF_HIP(h, hipEventRecord(h->ev_join[g - 1], cs[g]));
+        CF_HIP(h, hipStreamWaitEvent(st, h->ev_join[g - 1], 0));
+    }
+    return CF_OK;
+}
+
+static int cista_chain(cf_handle* h, const float* ev, const float* img, const float* c_prev, const float* z_prev,
+                       const float* h_prev, const float* cc_prev, float* I_out, float* c_out, float* z_out,
+                       float* h_out, float* cc_out, hipStream_t st) {
     const int B = h->B, H = h->H, W = h->W, hh = h->h, ww = h->w, bc = h->bc, bins = h->cfg.num_bins;
     const long HW = (long)H * W, hw = (long)hh * ww;
     const int c2 = 2 * bc;
