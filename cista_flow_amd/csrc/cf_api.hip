@@ -922,6 +922,7 @@ extern "C" int cf_cista_forward(cf_handle* h, const float* ev, const float* img,
                                 const float* h_prev, const float* cc_prev, float* I_out, float* c_out, float* z_out,
                                 float* h_out, float* cc_out, void* stream) {
     if (!h) return CF_ERR_ARG;
+    h->win_b0 = h->win_n = 0;      // a failed call may have left a batch window behind
     if (!h->finalized || !h->has_cista) return h->fail(CF_ERR_STATE, "cf_cista_forward: CISTA weights not finalised");
     if (!ev || !img || !I_out || !c_out || !z_out || !h_out || !cc_out) return h->fail(CF_ERR_ARG, "cf_cista_forward: null pointer");
     if ((h_prev == nullptr) != (cc_prev == nullptr)) return h->fail(CF_ERR_ARG, "cf_cista_forward: h_prev/cc_prev must come together");
@@ -1282,6 +1283,7 @@ static int idnet_forward(cf_handle* h, const float* ev, const float* flow_init, 
 extern "C" int cf_flow_forward(cf_handle* h, const float* in0, const float* in1, const float* flow_init, float* flow_final,
                                float* flow_low, float* flow_preds, void* stream) {
     if (!h) return CF_ERR_ARG;
+    h->win_b0 = h->win_n = 0;      // a failed call may have left a batch window behind
     if (!h->finalized || !h->has_flow) return h->fail(CF_ERR_STATE, "cf_flow_forward: flow-net weights not finalised");
     if (h->cfg.mode == CF_MODE_CISTA) return h->fail(CF_ERR_UNSUPPORTED, "cf_flow_forward: handle has no flow network");
     if (!in0 || !flow_final) return h->fail(CF_ERR_ARG, "cf_flow_forward: null pointer");
@@ -1300,6 +1302,7 @@ extern "C" int cf_step(cf_handle* h, const float* in0, const float* in1, const f
                        const float* cc_prev, float* I_out, float* flow_final, float* flow_low, float* flow_preds,
                        float* z_warped_out, float* c_out, float* z_out, float* h_out, float* cc_out, void* stream) {
     if (!h) return CF_ERR_ARG;
+    h->win_b0 = h->win_n = 0;      // a failed call may have left a batch window behind
     if (!h->finalized || !h->has_cista || !h->has_flow) return h->fail(CF_ERR_STATE, "cf_step: weights not finalised");
     if (h->cfg.mode == CF_MODE_CISTA) return h->fail(CF_ERR_UNSUPPORTED, "cf_step: handle has no flow network");
     if (h->cfg.mode == CF_MODE_IDNET && !in1) in1 = in0;
