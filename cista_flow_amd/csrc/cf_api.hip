@@ -97,6 +97,9 @@ struct cf_handle {
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};   // library-owned side streams
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     float *fmap1 = nullptr, *emap = nullptr, *fcat = nullptr, *pfmap2 = nullptr, *net = nullptr, *inp = nullptr;
+    // ERAFT: the driver's in0 of step t is its in1 of step t-1 (test_with_flow.py:144-149), so fnet(in0) is the feature
+    // map the previous step left in pfmap2.  cf_hint_prev_grid() arms the reuse for the next cf_step / cf_flow_forward.
+    bool fmap2_valid = false, reuse_next = false;
     float* corr[4] = {nullptr, nullptr, nullptr, nullptr};
     int clh[4] = {0, 0, 0, 0}, clw[4] = {0, 0, 0, 0};
     float *coords1 = nullptr, *corrfeat = nullptr, *c1buf = nullptr, *mcat = nullptr, *e1buf = nullptr, *f1buf = nullptr,
@@ -470,6 +473,7 @@ extern "C" int cf_load_weights(cf_handle* h, const char* name, const void* dev_p
 
 extern "C" int cf_finalize_weights(cf_handle* h, void* stream) {
     if (!h) return CF_ERR_ARG;
+    h->fmap2_valid = false;       // cached ERAFT feature maps belong to the old weights
     hipStream_t st = static_cast<hipStream_t>(stream);
     CF_HIP(h, hipSetDevice(h->cfg.device));
     for (void* p : h->owned) (void)hipFree(p);
@@ -1053,8 +1057,16 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
         if ((rc = encoder_forward(h, "event_flownet.fnet", false, img, 1, 2.f, -1.f, h->fmap1, nullptr, 1, sx0))) return rc;
         if ((rc = encoder_forward(h, "event_flownet.cnet", true, img, 1, 2.f, -1.f, h->net, h->inp, 2, sx1))) return rc;
     } else {
-        if ((rc = encoder_forward(h, "event_flownet.fnet", false, ev, bins, 1.f, 0.f, h->fmap1, nullptr, 0, st))) return rc;
-        if ((rc = encoder_forward(h, "event_flownet.fnet", false, img, bins, 1.f, 0.f, h->pfmap2, nullptr, 1, sx0))) return rc;
+        const bool reuse = h->reuse_next && h->fmap2_valid;
+        h->reuse_next = false;
+        h->fmap2_valid = false;
+        if (reuse) {
+            std::swap(h->fmap1, h->pfmap2);      // fnet(in0) == fnet(previous in1): same kernels on the same bytes
+            if ((rc = encoder_forward(h, "event_flownet.fnet", false, img, bins, 1.f, 0.f, h->pfmap2, nullptr, 1, st))) return rc;
+        } else {
+            if ((rc = encoder_forward(h, "event_flownet.fnet", false, ev, bins, 1.f, 0.f, h->fmap1, nullptr, 0, st))) return rc;
+            if ((rc = encoder_forward(h, "event_flownet.fnet", false, img, bins, 1.f, 0.f, h->pfmap2, nullptr, 1, sx0))) return rc;
+        }
         if ((rc = encoder_forward(h, "event_flownet.cnet", true, img, bins, 1.f, 0.f, h->net, h->inp, 2, sx1))) return rc;
     }
     // cnet-only consumers stay on its stream: iteration-invariant `inp` part of the six GRU convolutions
@@ -1188,6 +1200,7 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
         // flow_init of the returned dict = coords1 - coords0 at 1/8 resolution (DCEIFlow.py:297)
         CF_HIP(h, launch_upflow(h->coords1, B, h8, w8, 1, flow_low, nullptr, 0, 0, 0, 0, nullptr, st));
     }
+    h->fmap2_valid = eraft;
     return CF_OK;
 }
 
@@ -1297,6 +1310,15 @@ extern "C" int cf_flow_forward(cf_handle* h, const float* in0, const float* in1,
 // ---------------------------------------------------------------------------------------------
 // a5 wrapper   e2v_model.py:144-196
 // ---------------------------------------------------------------------------------------------
+// ERAFT only: declares that in0 of the NEXT cf_step / cf_flow_forward on this handle holds exactly the bytes in1 of
+// the previous one held, so its feature map is reused instead of recomputed.  One-shot; ignored when there is no
+// previous ERAFT step (or it failed).
+extern "C" int cf_hint_prev_grid(cf_handle* h, int same_as_previous_in1) {
+    if (!h) return CF_ERR_ARG;
+    h->reuse_next = same_as_previous_in1 != 0 && h->cfg.mode == CF_MODE_ERAFT;
+    return CF_OK;
+}
+
 extern "C" int cf_step(cf_handle* h, const float* in0, const float* in1, const float* rec_img0, const float* flow_init,
                        const float* gt_flow, const float* c_prev, const float* z_prev, const float* h_prev,
                        const float* cc_prev, float* I_out, float* flow_final, float* flow_low, float* flow_preds,

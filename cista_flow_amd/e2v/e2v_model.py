@@ -193,6 +193,8 @@ class ERAFTCistaNet(_HipFlowRec):
         self.event_flownet = ERAFT(args)
         self.flow_iters = 12         # ERAFT.forward default iters (eraft.py:114)
         self._backend = None
+        self.reuse_prev_features = True   # see forward()
+        self._last_ev = None
 
     def forward(self, batch_data, states, batch_gt=dict([])):
         '''batch_data: event_voxel_old, event_voxel [B,bins,H,W], rec_img0 [B,1,H,W]; batch_gt: optional gt_flow.'''
@@ -204,7 +206,17 @@ class ERAFTCistaNet(_HipFlowRec):
         _lib.check_f32_cuda(ev_old, "event_voxel_old", (B, self.num_bins, H, W))
         _lib.check_f32_cuda(ev, "event_voxel", (B, self.num_bins, H, W))
         _lib.check_f32_cuda(rec0, "rec_img0", (B, 1, H, W))
-        return self._step(ev_old, ev, rec0, states, None, batch_gt.get('gt_flow'))
+        # The driver carries `evs_old = evs` (test_with_flow.py:144-149): when event_voxel_old IS the tensor object that
+        # was event_voxel in the previous call (and has not been written since), fnet's feature map of it is still in
+        # the handle and is reused.  Holding the reference keeps that memory from being recycled under us.
+        last = getattr(self, "_last_ev", None)
+        reuse = (self.reuse_prev_features and last is not None and last[0] is ev_old and last[1] == ev_old._version
+                 and last[2] == B and states is not None)
+        h = self._be().get(B, ev.device)
+        h.check(h.lib.cf_hint_prev_grid(h.h, 1 if reuse else 0), "cf_hint_prev_grid")
+        out = self._step(ev_old, ev, rec0, states, None, batch_gt.get('gt_flow'))
+        self._last_ev = (ev, ev._version, B)
+        return out
 
 
 class IDCistaNet(_HipFlowRec):

@@ -19,7 +19,7 @@ SYMBOLS = [
     "cf_create", "cf_destroy", "cf_last_error", "cf_workspace_bytes", "cf_load_weights",
     "cf_finalize_weights", "cf_warp", "cf_cista_forward", "cf_flow_forward", "cf_step",
     "cf_op_conv2d", "cf_op_instance_norm_relu", "cf_op_corr_lookup", "cf_op_nchw_to_nhwc",
-    "cf_op_nhwc_to_nchw", "cf_profile_enable", "cf_profile_read", "cf_conv_tile_name", "cf_profile_report", "cf_op_conv2d_bench", "cf_events_to_voxel", "cf_op_conv2d_inorm_stats", "cf_quantize_u8",
+    "cf_op_nhwc_to_nchw", "cf_profile_enable", "cf_profile_read", "cf_conv_tile_name", "cf_profile_report", "cf_op_conv2d_bench", "cf_events_to_voxel", "cf_op_conv2d_inorm_stats", "cf_quantize_u8", "cf_hint_prev_grid",
 ]
 
 
@@ -87,6 +87,8 @@ def load():
     lib.cf_events_to_voxel.restype = i
     lib.cf_quantize_u8.argtypes = [fp, fp, C.c_longlong, vp]
     lib.cf_quantize_u8.restype = i
+    lib.cf_hint_prev_grid.argtypes = [vp, i]
+    lib.cf_hint_prev_grid.restype = i
     lib.cf_profile_enable.argtypes = [vp, i]
     lib.cf_profile_enable.restype = i
     lib.cf_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong), i]

@@ -94,6 +94,12 @@ int cf_cista_forward(cf_handle* h, const float* ev, const float* img, const floa
 int cf_flow_forward(cf_handle* h, const float* in0, const float* in1, const float* flow_init, float* flow_final,
                     float* flow_low, float* flow_preds, void* stream);
 
+/* a14  ERAFT driver carry (test_with_flow.py:144-149: `event_voxel_old` of frame t is `event_voxel` of frame t-1).
+ * Declares that in0 of the NEXT cf_step / cf_flow_forward holds the same bytes as in1 of the previous one, so fnet(in0)
+ * is taken from the previous step instead of being recomputed (bit-identical: same kernels on the same input).
+ * One-shot; a no-op for the other modes and when there is no previous step. */
+int cf_hint_prev_grid(cf_handle* h, int same_as_previous_in1);
+
 /* a5  one reconstructed frame: flow net -> any() -> warp I, warp Z -> CISTA-LSTC
  * (e2v/e2v_model.py:144-196).  gt_flow (nullable) overrides the estimated flow for the warp
  * (e2v_model.py:181-182).  z_warped_out (nullable unless z_prev != NULL) receives the warped

@@ -358,3 +358,30 @@ def test_idnet_f16_precision_mode(gpu):
     print("idnet 260x346 worst rel err  f16:", w16, " f16x3:", w3)
     assert max(w3.values()) < 3e-4, w3
     assert max(w16.values()) < 1e-2, w16
+
+
+def test_eraft_prev_feature_reuse_is_bit_identical(gpu):
+    """ERAFT driver carry (test_with_flow.py:144-149): when event_voxel_old is the previous call's event_voxel tensor,
+    fnet's feature map is reused (cf_hint_prev_grid) -- results must equal the recomputing path bit for bit, and an
+    in-place write to the carried tensor must switch the reuse off."""
+    from cista_flow_amd.e2v.e2v_model import ERAFTCistaNet
+    H, W, B = 100, 124, 2
+    outs = {}
+    for reuse in (False, True):
+        m = ERAFTCistaNet(args_for(H, W)).eval()
+        m.reuse_prev_features = reuse
+        wu.fill_module(m, 31)
+        m = m.to(gpu)
+        evs = [wu.synth_events(B, 5, H, W, 700 + t).to(gpu) for t in range(5)]
+        states, prev, res = None, torch.zeros(B, 1, H, W, device=gpu), []
+        with torch.no_grad():
+            for t in range(1, 5):
+                if t == 3:
+                    evs[2].mul_(1.0)          # in-place op on the carried tensor: version bump, reuse must be skipped
+                I, bf, states = m({"event_voxel": evs[t], "event_voxel_old": evs[t - 1], "rec_img0": prev}, states, {})
+                res.append((I.clone(), bf["flow_final"].clone(), states[1].clone()))
+                prev = I.clone()
+        outs[reuse] = res
+    for a, b in zip(outs[False], outs[True]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
