@@ -385,3 +385,47 @@ def test_eraft_prev_feature_reuse_is_bit_identical(gpu):
     for a, b in zip(outs[False], outs[True]):
         for x, y in zip(a, b):
             assert torch.equal(x, y)
+
+
+def test_eraft_standalone_with_flow_init_vs_oracle(gpu):
+    """ERAFT(cfgs).forward(image1, image2, iters, flow_init) (eraft.py:114) as a stand-alone module, warm-started."""
+    from cista_flow_amd.ERAFT.eraft import ERAFT
+    from oracle import cista_oracle as orc
+    H, W, B = 100, 124, 2
+    net = ERAFT(args_for(H, W)).eval()
+    wu.fill_module(net, 17)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.to(gpu)
+    a, b = wu.synth_events(B, 5, H, W, 41), wu.synth_events(B, 5, H, W, 42)
+    with torch.no_grad():
+        g1 = net(a.to(gpu), b.to(gpu), iters=5)
+        o1 = orc.eraft_forward(sd, a, b, iters=5, prefix="")
+        g2 = net(b.to(gpu), a.to(gpu), iters=5, flow_init=g1["flow_init"])
+        o2 = orc.eraft_forward(sd, b, a, iters=5, flow_init=o1["flow_init"], prefix="")
+    for g, o in ((g1, o1), (g2, o2)):
+        assert gu.rel_err(g["flow_final"].cpu(), o["flow_final"]) < TOL
+        assert gu.rel_err(g["flow_init"].cpu(), o["flow_init"]) < TOL
+        assert len(g["flow_preds"]) == 5
+        assert gu.rel_err(g["flow_preds"][-1].cpu(), o["flow_preds"][-1]) < TOL
+
+
+def test_idedeqido_standalone_vs_oracle(gpu):
+    """IDEDEQIDO(config).forward(event_bins, flow_init) (idedeq.py:124) as a stand-alone module, with the next_flow carry."""
+    from types import SimpleNamespace
+    from cista_flow_amd.idn.idedeq import IDEDEQIDO
+    from oracle import cista_oracle as orc
+    H, W, B = 68, 92, 2
+    net = IDEDEQIDO(SimpleNamespace(update_iters=1, pred_next_flow=True, image_dim=[H, W], num_bins=5)).eval()
+    wu.fill_module(net, 23)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.to(gpu)
+    e1, e2 = wu.synth_events(B, 5, H, W, 51), wu.synth_events(B, 5, H, W, 52)
+    with torch.no_grad():
+        g1 = net(e1.to(gpu))
+        o1 = orc.idnet_forward(sd, e1, prefix="")
+        g2 = net(e2.to(gpu), flow_init=g1["next_flow"])
+        o2 = orc.idnet_forward(sd, e2, flow_init=o1["next_flow"], prefix="")
+    for g, o in ((g1, o1), (g2, o2)):
+        for k in ("flow_final", "next_flow", "delta_flow"):
+            assert gu.rel_err(g[k].cpu(), o[k]) < TOL, k
+        assert gu.rel_err(g["flow_preds"][0].cpu(), o["flow_preds"][0]) < TOL
