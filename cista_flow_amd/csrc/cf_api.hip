@@ -96,6 +96,7 @@ struct cf_handle {
     // library-owned side streams, forked from / joined to the caller's stream with events
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};   // library-owned side streams
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_upf = nullptr, ev_up = nullptr;   // intermediate up-sampling on side stream 1 (fork / done)
     float *fmap1 = nullptr, *emap = nullptr, *fcat = nullptr, *pfmap2 = nullptr, *net = nullptr, *inp = nullptr;
     // ERAFT: the driver's in0 of step t is its in1 of step t-1 (test_with_flow.py:144-149), so fnet(in0) is the feature
     // map the previous step left in pfmap2.  cf_hint_prev_grid() arms the reuse for the next cf_step / cf_flow_forward.
@@ -696,6 +697,8 @@ extern "C" int cf_create(cf_handle** out, const cf_config* cfg) {
         ok = ok && hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming) == hipSuccess;
     }
     ok = ok && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&h->ev_upf, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         (void)hipFree(h->arena_mem);
         delete h;
@@ -720,6 +723,8 @@ extern "C" void cf_destroy(cf_handle* h) {
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_upf) (void)hipEventDestroy(h->ev_upf);
+    if (h->ev_up) (void)hipEventDestroy(h->ev_up);
     if (h->phases) {
         h->phase_collect();
         if (h->ph_n > 0)
@@ -1118,6 +1123,10 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
     CF_HIP(h, launch_coords_init(h->coords1, flow_init, B, h8, w8, st));
     if (flag) CF_HIP(h, hipMemsetAsync(flag, 0, sizeof(int), st));
     const int iters = h->cfg.iters;
+    // The up-sampled flow of the intermediate iterations (flow_preds) is nobody's input: it is produced on side stream
+    // 1 while the next iteration runs.  It reads net / coords1, which the next iteration updates in place, so the main
+    // stream waits for it (up_pending) right before the first such write -- by then it has long finished.
+    bool up_pending = false;
     for (int it = 0; it < iters; ++it) {
         // corr = corr_fn(coords1); flow = coords1 - coords0
         LookupParams lp;
@@ -1163,6 +1172,10 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
             set_aux0(a, h->net, 128, N * 128);
             set_out2(a, h->rh, 128, N * 128);
             CF_HIP(h, run_conv(h, a, B, st));
+            if (up_pending) {      // q writes net in place
+                CF_HIP(h, hipStreamWaitEvent(st, h->ev_up, 0));
+                up_pending = false;
+            }
             ConvParams q = nhwc_conv(qq, {{h->rh, 128, 128, N * 128}, {h->motion, 128, 128, N * 128}}, h8, w8, h8, w8, 1, pT, pL, 0, h->net, 128, N * 128, EPI_GRU_Q);
             q.bias = nullptr;
             q.addend = pre + 256; q.addend_ld = 384; q.addend_bs = N * 384;
@@ -1179,23 +1192,34 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
         CF_HIP(h, run_conv(h, h2, B, st));
         const bool last = it == iters - 1;
         float* up = flow_preds ? flow_preds + (long)it * B * 2 * h->Hp * h->Wp : nullptr;
+        hipStream_t su = st;
+        if (!last && up && !h->serial) {
+            su = sx1;
+            CF_HIP(h, hipEventRecord(h->ev_upf, st));
+            CF_HIP(h, hipStreamWaitEvent(su, h->ev_upf, 0));
+        }
         if (!eraft) {
             // upflow8 + unpad   DCEIFlow.py:222-227
             if (last || up)
                 CF_HIP(h, launch_upflow(h->coords1, B, h8, w8, 8, up, last ? flow_final : nullptr, h->H, h->W, h->padH, h->padW,
-                                        last ? flag : nullptr, st));
+                                        last ? flag : nullptr, su));
         } else if (last || up) {
             // mask = .25 * mask(net) (update.py:105) + learned convex up-sampling (eraft.py:77-88).  The reference
             // evaluates this on all 12 iterations; only iterations whose up-flow is requested are computed here.
             ConvParams m0 = nhwc_conv(h->conv["mask.0"], {{h->net, 128, 128, N * 128}}, h8, w8, h8, w8, 1, 1, 1, 0, h->mask1, 256, N * 256, EPI_RELU);
-            CF_HIP(h, run_conv(h, m0, B, st));
+            CF_HIP(h, run_conv(h, m0, B, su));
             ConvParams m2 = nhwc_conv(h->conv["mask.2"], {{h->mask1, 256, 256, N * 256}}, h8, w8, h8, w8, 1, 0, 0, 0, h->maskbuf, 576, N * 576, EPI_BIAS_SCALE);
             m2.scale = 0.25f;
-            CF_HIP(h, run_conv(h, m2, B, st));
+            CF_HIP(h, run_conv(h, m2, B, su));
             CF_HIP(h, launch_convex_upsample(h->coords1, 0, h->maskbuf, 576, B, h8, w8, up, last ? flow_final : nullptr, h->H,
-                                             h->W, h->padH, h->padW, last ? flag : nullptr, nullptr, nullptr, st));
+                                             h->W, h->padH, h->padW, last ? flag : nullptr, nullptr, nullptr, su));
+        }
+        if (su != st) {
+            CF_HIP(h, hipEventRecord(h->ev_up, su));
+            up_pending = true;
         }
     }
+    if (up_pending) CF_HIP(h, hipStreamWaitEvent(st, h->ev_up, 0));
     if (flow_low) {
         // flow_init of the returned dict = coords1 - coords0 at 1/8 resolution (DCEIFlow.py:297)
         CF_HIP(h, launch_upflow(h->coords1, B, h8, w8, 1, flow_low, nullptr, 0, 0, 0, 0, nullptr, st));
