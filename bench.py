@@ -89,13 +89,21 @@ def main():
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    dev = torch.device("cuda", local_rank)
+    # CF_BENCH_REHEARSE=1: control-flow rehearsal of the N > 1 path on a box with ONE GPU (all ranks share cuda:0,
+    # collectives go through gloo on host tensors).  Numbers from it mean nothing; it exists because the real
+    # RCCL run only happens on the driver's 8-GPU node.
+    rehearse = os.environ.get("CF_BENCH_REHEARSE") == "1"
+    dev = torch.device("cuda", 0 if rehearse else local_rank)
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    cdev = torch.device("cpu") if rehearse else dev      # where the timing all-reduce lives
 
     import weights_util as wu
     from cista_flow_amd.e2v.e2v_model import DCEIFlowCistaNet, ERAFTCistaNet, IDCistaNet
@@ -113,7 +121,7 @@ def main():
 
     state = {"prev": torch.zeros(B, 1, H, W, device=dev), "states": None, "i": 0, "flow_init": None}
 
-    def step():
+    def step(gather=True):
         ev = evs[state["i"] % R]
         if a.model == "eiflow":
             I, bf, st = model({"event_voxel": ev, "rec_img0": state["prev"]}, state["states"], {})
@@ -125,12 +133,12 @@ def main():
             state["flow_init"] = bf["next_flow"]
         state["prev"], state["states"] = I, st
         state["i"] += 1
-        if world > 1:
+        if world > 1 and gather:
             # collate the reconstructed frames of all ranks (RCCL all-gather over xGMI) off the critical path
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 I.record_stream(side)          # I was allocated on the main stream; keep it alive for the gather
-                state["gathered"] = collate_frames(I)
+                state["gathered"] = collate_frames(I.cpu() if rehearse else I)
         return I
 
     with torch.no_grad():
@@ -151,7 +159,7 @@ def main():
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        t = torch.tensor([el], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     assert torch.isfinite(state["prev"]).all(), "non-finite reconstruction"
@@ -163,9 +171,7 @@ def main():
         nprof = min(a.steps, 10)
         with torch.no_grad():
             for _ in range(nprof):
-                step()
-            if world > 1:
-                torch.cuda.current_stream().wait_stream(side)
+                step(gather=False)       # rank 0 only: no collective may be issued in this leg
         torch.cuda.synchronize()
         recs = h.profile_read()
         h.profile_enable(False)
@@ -233,7 +239,7 @@ def main():
                 dist.barrier()
             el2 = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([el2], device=dev, dtype=torch.float64)
+            t = torch.tensor([el2], device=cdev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el2 = float(t.item())
         # agreement of the two arithmetic modes on the last frame (both ran the same sequence length)
@@ -262,6 +268,7 @@ def main():
         }
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()          # rank 0 may still be in its roofline / printing leg
         dist.destroy_process_group()
 
 

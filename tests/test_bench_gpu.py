@@ -1,0 +1,26 @@
+"""bench.py control flow with more than one rank.  The real N > 1 run (RCCL over xGMI) only happens on the driver's
+8-GPU node; this rehearsal drives the same code with two ranks sharing the one GPU and gloo collectives
+(CF_BENCH_REHEARSE=1), so that a rank-asymmetric collective (a hang on the real node) is caught here."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_two_rank_rehearsal(gpu):
+    env = dict(os.environ, CF_BENCH_REHEARSE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--batch", "2", "--height", "128", "--width", "128"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]           # rank 0 prints exactly one JSON line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
+    assert out["value"] > 0 and out["roofline"] is not None and out["cpu_baseline"] is None
