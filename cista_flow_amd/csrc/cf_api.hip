@@ -84,7 +84,7 @@ struct cf_handle {
     void* arena_mem = nullptr;
     // CISTA
     float *xcat = nullptr, *x1 = nullptr, *ifbuf = nullptr, *z0 = nullptr, *xt = nullptr, *recx = nullptr,
-          *up = nullptr, *zeros = nullptr;
+          *up = nullptr, *upin = nullptr, *zeros = nullptr;
     // wrapper
     float *warpedI = nullptr, *zwarp = nullptr;
     int* flag = nullptr;
@@ -243,6 +243,7 @@ static void setup_buffers(cf_handle* H_) {
     s.xt = a.f(B * hw * bc);
     s.recx = a.f(B * hw * bc);
     s.up = a.f(B * HW * bc);
+    s.upin = a.f(B * HW * bc);
     s.warpedI = a.f(B * HW);
     s.zwarp = a.f(B * hw * 2 * bc);
     if (s.cfg.mode == CF_MODE_EIFLOW || s.cfg.mode == CF_MODE_ERAFT) {
@@ -808,6 +809,15 @@ static int cista_chain(cf_handle* h, const float* ev, const float* img, const fl
                        float* h_out, float* cc_out, hipStream_t st);
 
 // CF_CISTA_CHAINS = 1 | 2 | 4 forces the number of part-batch chains; default (0): chosen per geometry
+static int upsample_materialised() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("CF_UPSAMPLE_MAT");
+        v = e ? atoi(e) : 1;
+    }
+    return v;
+}
+
 static int cista_chains_env() {
     static int v = -1;
     if (v < 0) {
@@ -914,12 +924,23 @@ static int cista_chain(cf_handle* h, const float* ev, const float* img, const fl
     }
     // upsample x2 + reflect pad + conv + relu ; final conv + sigmoid   e2v_model.py:94-96
     {
-        ConvParams u = nhwc_conv(h->conv["cista.upsamp"], {{h_out, bc, bc, hw * bc}}, 2 * hh, 2 * ww, H, W, 1, 1, 1, 1, h->up,
-                                 bc, HW * bc, EPI_RELU);
-        u.a_mode = A_UPS2X;
-        u.Hsrc = hh;
-        u.Wsrc = ww;
-        CF_HIP(h, run_conv(h, u, B, st));
+        if (upsample_materialised() && H == 2 * hh && W == 2 * ww && h->cfg.precision == 0) {
+            // write the up-sampled tensor once (HBM-bound, ~25 us) so that the conv runs on the LDS-DMA kernel
+            // (~105 TFLOP/s) instead of the register-staged fused read (~85)
+            const long b0 = h->win_n > 0 ? h->win_b0 : 0;
+            const int bn = h->win_n > 0 ? h->win_n : B;
+            CF_HIP(h, launch_upsample2x_nhwc(h_out + b0 * hw * bc, bc, hw * bc, h->upin + b0 * HW * bc, bc, HW * bc, bn, hh, ww, bc, st));
+            ConvParams u = nhwc_conv(h->conv["cista.upsamp"], {{h->upin, bc, bc, HW * bc}}, H, W, H, W, 1, 1, 1, 1, h->up, bc,
+                                     HW * bc, EPI_RELU);
+            CF_HIP(h, run_conv(h, u, B, st));
+        } else {
+            ConvParams u = nhwc_conv(h->conv["cista.upsamp"], {{h_out, bc, bc, hw * bc}}, 2 * hh, 2 * ww, H, W, 1, 1, 1, 1, h->up,
+                                     bc, HW * bc, EPI_RELU);
+            u.a_mode = A_UPS2X;
+            u.Hsrc = hh;
+            u.Wsrc = ww;
+            CF_HIP(h, run_conv(h, u, B, st));
+        }
         ConvParams f = nhwc_conv(h->conv["cista.final"], {{h->up, bc, bc, HW * bc}}, H, W, H, W, 1, 1, 1, 1, I_out, 1, HW,
                                  EPI_SIGMOID);
         CF_HIP(h, run_conv(h, f, B, st));

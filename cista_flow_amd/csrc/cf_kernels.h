@@ -191,6 +191,10 @@ hipError_t launch_events_to_voxel(const double* events, const long* offsets, int
 hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int dst_ld, int B, int C, int HW, hipStream_t s);
 hipError_t launch_nhwc_to_nchw(const float* src, int src_ld, float* dst, int B, int C, int HW, hipStream_t s);
 
+// F.interpolate(x2, bilinear, align_corners=False) of an NHWC tensor [B][Hs][Ws][C] -> [B][2Hs][2Ws][C]
+hipError_t launch_upsample2x_nhwc(const float* src, int s_ld, long s_bs, float* dst, int d_ld, long d_bs, int B, int Hs, int Ws,
+                                  int C, hipStream_t s);
+
 // f-2: np.uint8(pred * 255.) of the reconstructed frames (test_with_flow.py:174)
 hipError_t launch_quantize_u8(const float* x, unsigned char* out, long n, hipStream_t s);
 

@@ -770,6 +770,55 @@ hipError_t launch_nhwc_to_nchw(const float* src, int src_ld, float* dst, int B, 
 }
 
 // ---------------------------------------------------------------------------
+// F.interpolate(size = 2h x 2w, bilinear, align_corners=False) of an NHWC tensor (base_layers.py:200-202), written out
+// so that the following reflect-padded 3x3 conv can read it through the LDS-DMA kernel.  Same tap / blend arithmetic
+// as the fused A_UPS2X read of the convolution kernel.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void upsample2x_nhwc_kernel(const float* __restrict__ src, int s_ld, long s_bs, float* __restrict__ dst,
+                                                              int d_ld, long d_bs, int B, int Hs, int Ws, int C) {
+    const int cq = C >> 2;
+    const int Ho = 2 * Hs, Wo = 2 * Ws;
+    const long total = (long)B * Ho * Wo * cq;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int c0 = (int)(gid % cq) * 4;
+    long t = gid / cq;
+    const int ox = (int)(t % Wo);
+    t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    float sy = ((float)oy + 0.5f) * 0.5f - 0.5f;
+    float sx = ((float)ox + 0.5f) * 0.5f - 0.5f;
+    sy = sy < 0.f ? 0.f : sy;
+    sx = sx < 0.f ? 0.f : sx;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < Hs - 1 ? 1 : 0);
+    const int x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
+    const float ly1 = sy - (float)y0, lx1 = sx - (float)x0;
+    const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+    const float* sb = src + (long)b * s_bs + c0;
+    const f32x4 v00 = *reinterpret_cast<const f32x4*>(sb + ((long)y0 * Ws + x0) * s_ld);
+    const f32x4 v01 = *reinterpret_cast<const f32x4*>(sb + ((long)y0 * Ws + x1) * s_ld);
+    const f32x4 v10 = *reinterpret_cast<const f32x4*>(sb + ((long)y1 * Ws + x0) * s_ld);
+    const f32x4 v11 = *reinterpret_cast<const f32x4*>(sb + ((long)y1 * Ws + x1) * s_ld);
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = ly0 * (lx0 * v00[e] + lx1 * v01[e]) + ly1 * (lx0 * v10[e] + lx1 * v11[e]);
+    *reinterpret_cast<f32x4*>(dst + (long)b * d_bs + ((long)oy * Wo + ox) * d_ld + c0) = v;
+}
+
+hipError_t launch_upsample2x_nhwc(const float* src, int s_ld, long s_bs, float* dst, int d_ld, long d_bs, int B, int Hs, int Ws,
+                                  int C, hipStream_t s) {
+    if (!src || !dst || B <= 0 || Hs <= 0 || Ws <= 0 || C <= 0 || (C % 4) != 0 || (s_ld % 4) != 0 || (d_ld % 4) != 0 ||
+        (s_bs % 4) != 0 || (d_bs % 4) != 0 || (reinterpret_cast<uintptr_t>(src) & 15) != 0 || (reinterpret_cast<uintptr_t>(dst) & 15) != 0)
+        return hipErrorInvalidValue;
+    const long total = (long)B * 4 * Hs * Ws * (C / 4);
+    hipLaunchKernelGGL(upsample2x_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, s_ld, s_bs, dst, d_ld, d_bs, B,
+                       Hs, Ws, C);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // f-2 output stage: np.uint8(pred * 255.)  (test_with_flow.py:174) -- fp32 product, truncation toward zero
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void quantize_u8_kernel(const float* __restrict__ x, unsigned char* __restrict__ out, long n) {
