@@ -293,14 +293,13 @@ __global__ __launch_bounds__(256) void inorm_apply_kernel(const float* __restric
                                                           int res_ld, long res_bs, const float* __restrict__ res_stats,
                                                           float* __restrict__ out, int out_ld, long out_bs, int B, int HW,
                                                           int C) {
+    // grid: x over the quads of one image (HW * C/4 < 2^31), y = image -- 32-bit index math only
     const int cq = C / 4;
-    const long total = (long)B * HW * cq;
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= total) return;
-    const int c0 = (int)(gid % cq) * 4;
-    const long pix = gid / cq;
-    const int p = (int)(pix % HW);
-    const int b = (int)(pix / HW);
+    const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (unsigned)HW * (unsigned)cq) return;
+    const int p = (int)(gid / (unsigned)cq);
+    const int c0 = (int)(gid - (unsigned)p * (unsigned)cq) * 4;
+    const int b = blockIdx.y;
     const f32x4 v = *reinterpret_cast<const f32x4*>(x + (long)b * bs + (long)p * ld + c0);
     f32x4 r;
     const float* st = stats + ((long)b * C + c0) * 2;
@@ -325,8 +324,9 @@ hipError_t launch_inorm_apply(const float* x, int ld, long bs, const float* stat
     if (!x || !stats || !out || (C % 4) != 0 || (ld % 4) != 0 || (out_ld % 4) != 0 || (bs % 4) != 0 || (out_bs % 4) != 0)
         return hipErrorInvalidValue;
     if (res && ((res_ld % 4) != 0 || (res_bs % 4) != 0)) return hipErrorInvalidValue;
-    const long total = (long)B * HW * (C / 4);
-    hipLaunchKernelGGL(inorm_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, ld, bs, stats, res,
+    const long per_image = (long)HW * (C / 4);
+    if (per_image >= 0x7FFFFFFFL || B > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(inorm_apply_kernel, dim3((unsigned)((per_image + 255) / 256), B), dim3(256), 0, s, x, ld, bs, stats, res,
                        res_ld, res_bs, res_stats, out, out_ld, out_bs, B, HW, C);
     return hipGetLastError();
 }
@@ -776,17 +776,15 @@ hipError_t launch_nhwc_to_nchw(const float* src, int src_ld, float* dst, int B, 
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void upsample2x_nhwc_kernel(const float* __restrict__ src, int s_ld, long s_bs, float* __restrict__ dst,
                                                               int d_ld, long d_bs, int B, int Hs, int Ws, int C) {
+    // grid: x = quads of one output row (Wo * C/4), y = output row, z = image -- no 64-bit divisions per thread
     const int cq = C >> 2;
-    const int Ho = 2 * Hs, Wo = 2 * Ws;
-    const long total = (long)B * Ho * Wo * cq;
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= total) return;
-    const int c0 = (int)(gid % cq) * 4;
-    long t = gid / cq;
-    const int ox = (int)(t % Wo);
-    t /= Wo;
-    const int oy = (int)(t % Ho);
-    const int b = (int)(t / Ho);
+    const int Wo = 2 * Ws;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Wo * cq) return;
+    const int ox = i / cq;
+    const int c0 = (i - ox * cq) * 4;
+    const int oy = blockIdx.y;
+    const int b = blockIdx.z;
     float sy = ((float)oy + 0.5f) * 0.5f - 0.5f;
     float sx = ((float)ox + 0.5f) * 0.5f - 0.5f;
     sy = sy < 0.f ? 0.f : sy;
@@ -797,14 +795,14 @@ __global__ __launch_bounds__(256) void upsample2x_nhwc_kernel(const float* __res
     const float ly1 = sy - (float)y0, lx1 = sx - (float)x0;
     const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
     const float* sb = src + (long)b * s_bs + c0;
-    const f32x4 v00 = *reinterpret_cast<const f32x4*>(sb + ((long)y0 * Ws + x0) * s_ld);
-    const f32x4 v01 = *reinterpret_cast<const f32x4*>(sb + ((long)y0 * Ws + x1) * s_ld);
-    const f32x4 v10 = *reinterpret_cast<const f32x4*>(sb + ((long)y1 * Ws + x0) * s_ld);
-    const f32x4 v11 = *reinterpret_cast<const f32x4*>(sb + ((long)y1 * Ws + x1) * s_ld);
+    const f32x4 v00 = *reinterpret_cast<const f32x4*>(sb + (long)(y0 * Ws + x0) * s_ld);
+    const f32x4 v01 = *reinterpret_cast<const f32x4*>(sb + (long)(y0 * Ws + x1) * s_ld);
+    const f32x4 v10 = *reinterpret_cast<const f32x4*>(sb + (long)(y1 * Ws + x0) * s_ld);
+    const f32x4 v11 = *reinterpret_cast<const f32x4*>(sb + (long)(y1 * Ws + x1) * s_ld);
     f32x4 v;
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = ly0 * (lx0 * v00[e] + lx1 * v01[e]) + ly1 * (lx0 * v10[e] + lx1 * v11[e]);
-    *reinterpret_cast<f32x4*>(dst + (long)b * d_bs + ((long)oy * Wo + ox) * d_ld + c0) = v;
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst + (long)b * d_bs + (long)(oy * Wo + ox) * d_ld + c0));
 }
 
 hipError_t launch_upsample2x_nhwc(const float* src, int s_ld, long s_bs, float* dst, int d_ld, long d_bs, int B, int Hs, int Ws,
@@ -812,9 +810,10 @@ hipError_t launch_upsample2x_nhwc(const float* src, int s_ld, long s_bs, float* 
     if (!src || !dst || B <= 0 || Hs <= 0 || Ws <= 0 || C <= 0 || (C % 4) != 0 || (s_ld % 4) != 0 || (d_ld % 4) != 0 ||
         (s_bs % 4) != 0 || (d_bs % 4) != 0 || (reinterpret_cast<uintptr_t>(src) & 15) != 0 || (reinterpret_cast<uintptr_t>(dst) & 15) != 0)
         return hipErrorInvalidValue;
-    const long total = (long)B * 4 * Hs * Ws * (C / 4);
-    hipLaunchKernelGGL(upsample2x_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, s_ld, s_bs, dst, d_ld, d_bs, B,
-                       Hs, Ws, C);
+    if (2 * Hs > 65535 || B > 65535) return hipErrorInvalidValue;
+    const int row = 2 * Ws * (C / 4);
+    hipLaunchKernelGGL(upsample2x_nhwc_kernel, dim3((unsigned)((row + 255) / 256), 2 * Hs, B), dim3(256), 0, s, src, s_ld, s_bs, dst, d_ld,
+                       d_bs, B, Hs, Ws, C);
     return hipGetLastError();
 }
 

@@ -16,7 +16,8 @@ def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     src = os.path.join(ROOT, "gpurun_out", "prof")
     dst = os.path.join(ROOT, "profiles")
-    stats = glob.glob(src + "/stats/**/*kernel_stats.csv", recursive=True)
+    # gpurun merges into the local gpurun_out/, so files of earlier runs linger: take the newest
+    stats = sorted(glob.glob(src + "/stats/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime, reverse=True)
     assert stats, "no kernel_stats.csv under gpurun_out/prof/stats"
     shutil.copy(stats[0], os.path.join(dst, tag + "_kernel_stats.csv"))
     rows = list(csv.DictReader(open(stats[0])))
