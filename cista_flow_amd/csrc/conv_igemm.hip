@@ -251,9 +251,11 @@ __device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned of
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
 }
 
+// it0 / it1: which of the lane's four quads (pixel rows (lane >> 3) + 8 it) to finish; nparts / pstride: the patch is the
+// sum of nparts partial patches pstride floats apart (split-K tiles: every wave finishes its share of the rows).
 template <int EB, int CLS>
 __device__ __forceinline__ void patch_tail_fast(const ConvParams& p, const float* sW, int b, int mrow0, int nbase, int lane,
-                                                int M) {
+                                                int M, int it0, int it1, int nparts, int pstride) {
     const int n = nbase + (lane & 7) * 4;
     const int mb = mrow0 + (lane >> 3);
     const int epi = p.epi;
@@ -273,13 +275,13 @@ __device__ __forceinline__ void patch_tail_fast(const ConvParams& p, const float
     const bool zr_hi = epi == EPI_GRU_ZR && n >= p.split;          // r half of the z|r conv (per quad)
     const bool sp_hi = epi == EPI_TANH_RELU_SPLIT && n >= p.split;
     const unsigned n4_hi = 4u * (unsigned)(n - p.split);
-#pragma unroll
-    for (int h = 0; h < 4; h += EB) {
+#pragma unroll 1
+    for (int h = it0; h < it1; h += EB) {
         EpiAux x[EB];
 #pragma unroll
         for (int it = 0; it < EB; ++it) {
             const int m = mb + (h + it) * 8;
-            const bool ok = m < M;
+            const bool ok = m < M && h + it < it1;
             const unsigned um = (unsigned)m;
             const unsigned o0 = ok ? um * (4u * (unsigned)p.aux0_ld) + n4 : BUF_OOB;
             if constexpr (CLS == 1) {
@@ -308,9 +310,15 @@ __device__ __forceinline__ void patch_tail_fast(const ConvParams& p, const float
 #pragma unroll
         for (int it = 0; it < EB; ++it) {
             const int m = mb + (h + it) * 8;
-            const bool ok = m < M;
+            const bool ok = m < M && h + it < it1;
             const unsigned um = (unsigned)m;
-            const f32x4 acc = *reinterpret_cast<const f32x4*>(sW + ((lane >> 3) + (h + it) * 8) * EPI_S + (lane & 7) * 4);
+            const int srow = ((lane >> 3) + ((h + it) & 3) * 8) * EPI_S + (lane & 7) * 4;
+            f32x4 acc = *reinterpret_cast<const f32x4*>(sW + srow);
+            for (int k = 1; k < nparts; ++k) {       // same order as the register reduction it replaces
+                const f32x4 t = *reinterpret_cast<const f32x4*>(sW + k * pstride + srow);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += t[e];
+            }
             const EpiAux& a = x[it];
             f32x4 v, o;
 #pragma unroll
@@ -443,23 +451,30 @@ __device__ __forceinline__ void patch_tail_fast(const ConvParams& p, const float
 }
 
 // generic tail: any alignment, partial quads, strided outputs (out_cs != 1), EPI_ADD_AUX
-__device__ __forceinline__ void patch_tail(const ConvParams& p, const float* sW, int b, int mrow0, int nbase, int lane, int M) {
+__device__ __forceinline__ void patch_tail(const ConvParams& p, const float* sW, int b, int mrow0, int nbase, int lane, int M,
+                                           int it0 = 0, int it1 = 4, int nparts = 1, int pstride = 0) {
     if (p.epi_vec && nbase + 32 <= p.cout) {      // wave-uniform
         const int epi = p.epi;
         const bool one_aux = epi == EPI_SUB_FROM_AUX || epi == EPI_ADD_AUX_SHRINK || epi == EPI_RELU_ADD_AUX ||
                              epi == EPI_RELU_ADD_AUX_RELU || epi == EPI_LSTM_CELL;
-        if (epi == EPI_LSTC) patch_tail_fast<1, 3>(p, sW, b, mrow0, nbase, lane, M);
-        else if (p.addend || epi == EPI_GRU_ZR || epi == EPI_GRU_Q) patch_tail_fast<2, 2>(p, sW, b, mrow0, nbase, lane, M);
-        else if (one_aux) patch_tail_fast<4, 1>(p, sW, b, mrow0, nbase, lane, M);
-        else patch_tail_fast<4, 0>(p, sW, b, mrow0, nbase, lane, M);
+        if (epi == EPI_LSTC) patch_tail_fast<1, 3>(p, sW, b, mrow0, nbase, lane, M, it0, it1, nparts, pstride);
+        else if (p.addend || epi == EPI_GRU_ZR || epi == EPI_GRU_Q) patch_tail_fast<2, 2>(p, sW, b, mrow0, nbase, lane, M, it0, it1, nparts, pstride);
+        else if (one_aux) patch_tail_fast<4, 1>(p, sW, b, mrow0, nbase, lane, M, it0, it1, nparts, pstride);
+        else patch_tail_fast<4, 0>(p, sW, b, mrow0, nbase, lane, M, it0, it1, nparts, pstride);
         return;
     }
     const int nb = nbase + (lane & 7) * 4;
     const int mb = mrow0 + (lane >> 3);
 #pragma unroll 1
-    for (int it = 0; it < 4; ++it) {
+    for (int it = it0; it < it1; ++it) {
         const int m = mb + it * 8;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(sW + ((lane >> 3) + it * 8) * EPI_S + (lane & 7) * 4);
+        const int srow = ((lane >> 3) + it * 8) * EPI_S + (lane & 7) * 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(sW + srow);
+        for (int k = 1; k < nparts; ++k) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(sW + k * pstride + srow);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += t[e];
+        }
         if (m < M && nb < p.cout) epilogue4(p, b, m, nb, v);
     }
 }
@@ -870,6 +885,20 @@ __global__ __launch_bounds__(256, igemm_waves(BM, BN, WAVES_M, WAVES_N, WK, KCW)
     }
 
     // ---- split-K: fold the partial accumulators of the wk > 0 waves into the wk == 0 wave ----
+    if (WK > 1 && !p.st_partial) {
+        // Split-K tail shared by all waves: every wave parks its partial 32x32 tile in patch layout, and after the barrier
+        // finishes 4/WK of the patch's row groups (summing the WK partials on the way, in the order k = 0..WK-1).
+        // Before, the wk > 0 waves left and one wave per sub-tile did the whole tail.
+        static_assert(WK == 1 || (TM == 1 && TN == 1), "split-K tiles hold one sub-tile per wave");
+        static_assert(WK * WMN * 32 * EPI_S <= SMEM, "partial patches must fit the stage buffers");
+        constexpr int PSTRIDE = WMN * 32 * EPI_S;
+        float* part = smem + wk * PSTRIDE + wmn * (32 * EPI_S);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_S + lr] = acc[0][0][r];
+        __syncthreads();
+        patch_tail(p, smem + wmn * (32 * EPI_S), b, m0 + wm * 32, n0 + wn * 32, lane, M, wk * (4 / WK), (wk + 1) * (4 / WK), WK, PSTRIDE);
+        return;
+    }
     if (WK > 1) {
         float* red = smem;
         if (wk > 0) {
@@ -1255,6 +1284,20 @@ void conv_dma_kernel(const ConvParams p) {
     wait_lgkm0();
     raw_barrier();          // every wave is done reading the ring before it is reused below
 
+    if (WK > 1 && !p.st_partial) {
+        // Split-K tail shared by all waves: every wave parks its partial 32x32 tile in patch layout, and after the barrier
+        // finishes 4/WK of the patch's row groups (summing the WK partials on the way, in the order k = 0..WK-1).
+        // Before, the wk > 0 waves left and one wave per sub-tile did the whole tail.
+        static_assert(WK == 1 || (TM == 1 && TN == 1), "split-K tiles hold one sub-tile per wave");
+        static_assert(WK * WMN * 32 * EPI_S <= SMEM, "partial patches must fit the stage buffers");
+        constexpr int PSTRIDE = WMN * 32 * EPI_S;
+        float* part = smem + wk * PSTRIDE + wmn * (32 * EPI_S);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_S + lr] = acc[0][0][r];
+        __syncthreads();
+        patch_tail(p, smem + wmn * (32 * EPI_S), b, m0 + wm * 32, n0 + wn * 32, lane, M, wk * (4 / WK), (wk + 1) * (4 / WK), WK, PSTRIDE);
+        return;
+    }
     if (WK > 1) {
         float* red = smem;
         if (wk > 0) {
