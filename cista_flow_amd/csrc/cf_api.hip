@@ -694,6 +694,8 @@ extern "C" int cf_create(cf_handle** out, const cf_config* cfg) {
         for (int i = 0; h->phases && i < 4; ++i) ok = ok && hipEventCreate(&h->ph_ev[i]) == hipSuccess;
     }
     for (int i = 0; i < 3; ++i) {
+        // aux[0], aux[1]: encoder / flow-branch / second CISTA chain; aux[2]: work nobody waits for inside the step
+        // (flow_preds up-sampling).  A low stream priority for aux[2] was measured: no effect.
         ok = ok && hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming) == hipSuccess;
     }
@@ -1215,7 +1217,7 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
         float* up = flow_preds ? flow_preds + (long)it * B * 2 * h->Hp * h->Wp : nullptr;
         hipStream_t su = st;
         if (!last && up && !h->serial) {
-            su = sx1;
+            su = h->aux[2];
             CF_HIP(h, hipEventRecord(h->ev_upf, st));
             CF_HIP(h, hipStreamWaitEvent(su, h->ev_upf, 0));
         }
