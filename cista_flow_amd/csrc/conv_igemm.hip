@@ -1000,7 +1000,7 @@ __device__ __forceinline__ void dma16_to_lds(__amdgpu_buffer_rsrc_t rs, float* l
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)lds_dst, 16, voff, soff, 0, 0);
 }
-__device__ __forceinline__ void wait_vmcnt_le(int n) {   // n is wave-uniform, <= 8
+__device__ __forceinline__ void wait_vmcnt_le(int n) {   // n is wave-uniform, <= 12
     switch (n) {
         case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
         case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
@@ -1010,7 +1010,11 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {   // n is wave-uniform, <
         case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
         case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
         case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;      // 0, and anything larger (safe)
     }
 }
 __device__ __forceinline__ void wait_vmcnt0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -1024,20 +1028,22 @@ __device__ __forceinline__ void raw_barrier() {
 // accumulator sub-tiles per wave, capped by what the LDS ring allows anyway (one wave per SIMD per workgroup).
 // Without it hipcc lets the tail code take registers the main loop does not need and halves the occupancy.
 constexpr int dma_stage_floats(int BM, int BN, int WK, int KCW) { return (BM + BN) * KCW * WK; }
-constexpr int dma_smem_floats(int BM, int BN, int WM, int WN, int WK, int KCW) {
-    const int ring = 3 * dma_stage_floats(BM, BN, WK, KCW);
+constexpr int dma_smem_floats(int BM, int BN, int WM, int WN, int WK, int KCW, int NBUF) {
+    const int ring = NBUF * dma_stage_floats(BM, BN, WK, KCW);
     const int wmn = WM * WN, tm = BM / (32 * WM), tn = BN / (32 * WN);
     const int tail = (WK - 1) * wmn * tm * tn * 1024 + wmn * 32 * EPI_S;
     return ring > tail ? ring : tail;
 }
-constexpr int dma_waves(int BM, int BN, int WM, int WN, int WK, int KCW) {
+constexpr int dma_waves(int BM, int BN, int WM, int WN, int WK, int KCW, int NBUF) {
     const int t = (BM / (32 * WM)) * (BN / (32 * WN));
     const int by_regs = t == 1 ? 5 : (t == 2 ? WPE2 : 3);
-    const int by_lds = (160 * 1024) / (4 * dma_smem_floats(BM, BN, WM, WN, WK, KCW));
+    const int by_lds = (160 * 1024) / (4 * dma_smem_floats(BM, BN, WM, WN, WK, KCW, NBUF));
     return by_regs < by_lds ? by_regs : by_lds;
 }
-template <int BM, int BN, int WAVES_M, int WAVES_N, int WK, int KCW>
-__global__ __launch_bounds__(256, dma_waves(BM, BN, WAVES_M, WAVES_N, WK, KCW))
+// NBUF: ring depth; NBUF - 1 stages are in flight ahead of the one being multiplied (3: default; 4: the small tiles,
+// whose ~12 KB stages otherwise leave too few bytes in flight per CU to cover the L2 latency at their load rate)
+template <int BM, int BN, int WAVES_M, int WAVES_N, int WK, int KCW, int NBUF = 3>
+__global__ __launch_bounds__(256, dma_waves(BM, BN, WAVES_M, WAVES_N, WK, KCW, NBUF))
 void conv_dma_kernel(const ConvParams p) {
     static_assert(WAVES_M * WAVES_N * WK == 4, "4 waves per workgroup");
 #ifdef CF_STAMP
@@ -1055,7 +1061,6 @@ void conv_dma_kernel(const ConvParams p) {
     constexpr int A_IT = (A_SLOTS + 255) / 256;
     constexpr int B_IT = (B_SLOTS + 255) / 256;
     constexpr int STAGE = (BM + BN) * KS;              // floats per ring slot
-    constexpr int NBUF = 3;
     constexpr int RED = (WK - 1) * WMN * TM * TN * 1024;
     constexpr int SMEM = (NBUF * STAGE > RED + WMN * 32 * EPI_S) ? NBUF * STAGE : RED + WMN * 32 * EPI_S;
 
@@ -1176,13 +1181,18 @@ void conv_dma_kernel(const ConvParams p) {
     tap_setup();
 
     // one stage: A_IT + B_IT wave-instructions per wave (a wave whose 64 slots lie past the tile issues nothing)
-    auto issue_stage = [&](int buf) __attribute__((always_inline)) {
+    // A stage is fetched in NP = A_IT + B_IT pieces (one wave-instruction each); issue_piece(buf, q) issues piece q and
+    // the last piece also advances the (wave-uniform) chunk iterator.  In the main loop the pieces are spread between
+    // the MFMA groups of the stage being multiplied: a DMA piece holds the wave's instruction stream for 60-185
+    // cycles, which then passes under MFMAs already queued instead of in front of them (+2-6 % per layer).
+    constexpr int NP = A_IT + B_IT;
+    auto issue_piece = [&](int buf, int q) __attribute__((always_inline)) {
         float* base = smem + buf * STAGE;
-        const __amdgpu_buffer_rsrc_t rs = make_rsrc(seg_base);
-        const unsigned ld4 = (unsigned)seg_ld * 4u, so = (unsigned)it_cs * 4u;
-#pragma unroll
-        for (int j = 0; j < A_IT; ++j) {
+        if (q < A_IT) {
+            const int j = q;
             if ((256 * j + 64 * wave) < A_SLOTS) {      // wave-uniform
+                const __amdgpu_buffer_rsrc_t rs = make_rsrc(seg_base);
+                const unsigned ld4 = (unsigned)seg_ld * 4u, so = (unsigned)it_cs * 4u;
                 const unsigned off = a_pix[j] < 0 ? BUF_OOB : (unsigned)a_pix[j] * ld4 + a_qoff[j];
 #ifndef CF_EXP_NOLOAD
                 dma16_to_lds(rs, base + (256 * j + 64 * wave) * 4, off, so);
@@ -1190,35 +1200,41 @@ void conv_dma_kernel(const ConvParams p) {
                 asm volatile("" ::"v"(off), "s"(so));
 #endif
             }
-        }
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            if ((256 * it + 64 * wave) < B_SLOTS)
+        } else {
+            const int it = q - A_IT;
+            if ((256 * it + 64 * wave) < B_SLOTS) {
 #ifndef CF_EXP_NOLOAD
                 dma16_to_lds(b_rsrc, base + BM * KS + (256 * it + 64 * wave) * 4, b_off[it], (unsigned)it_k * 4u);
 #else
                 asm volatile("" ::"v"(b_off[it]));
 #endif
-        }
-        // ---- advance the (wave-uniform) iterator ----
-        it_k += KS;
-        it_cs += KS;
-        if (it_cs >= seg_cn) {
-            it_cs = 0;
-            ++it_seg;
-            if (it_seg >= nseg) {
-                it_seg = 0;
-                ++it_kx;
-                if (it_kx >= kw_n) {
-                    it_kx = 0;
-                    ++it_ky;
-                }
-                tap_setup();
             }
-            seg_base = sel3(p.in, it_seg) + (long)b * (it_seg == 0 ? p.seg_bs[0] : (it_seg == 1 ? p.seg_bs[1] : p.seg_bs[2]));
-            seg_ld = it_seg == 0 ? p.seg_ld[0] : (it_seg == 1 ? p.seg_ld[1] : p.seg_ld[2]);
-            seg_cn = it_seg == 0 ? p.seg_c[0] : (it_seg == 1 ? p.seg_c[1] : p.seg_c[2]);
         }
+        if (q == NP - 1) {
+            // ---- advance the (wave-uniform) iterator ----
+            it_k += KS;
+            it_cs += KS;
+            if (it_cs >= seg_cn) {
+                it_cs = 0;
+                ++it_seg;
+                if (it_seg >= nseg) {
+                    it_seg = 0;
+                    ++it_kx;
+                    if (it_kx >= kw_n) {
+                        it_kx = 0;
+                        ++it_ky;
+                    }
+                    tap_setup();
+                }
+                seg_base = sel3(p.in, it_seg) + (long)b * (it_seg == 0 ? p.seg_bs[0] : (it_seg == 1 ? p.seg_bs[1] : p.seg_bs[2]));
+                seg_ld = it_seg == 0 ? p.seg_ld[0] : (it_seg == 1 ? p.seg_ld[1] : p.seg_ld[2]);
+                seg_cn = it_seg == 0 ? p.seg_c[0] : (it_seg == 1 ? p.seg_c[1] : p.seg_c[2]);
+            }
+        }
+    };
+    auto issue_stage = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) issue_piece(buf, q);
     };
     // DMA wave-instructions THIS wave issues per stage (what the counted vmcnt leaves in flight)
     int nl = 0;
@@ -1227,10 +1243,12 @@ void conv_dma_kernel(const ConvParams p) {
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) nl += ((256 * it + 64 * wave) < B_SLOTS) ? 1 : 0;
 
-    issue_stage(0);
-    if (nck > 1) issue_stage(1);
+    constexpr int DIST = NBUF - 1;                 // prefetch distance in stages
+#pragma unroll
+    for (int d = 0; d < DIST; ++d)
+        if (d < nck) issue_stage(d);
 
-    int rbuf = 0, wbuf = 2;
+    int rbuf = 0, wbuf = DIST;
 #ifdef CF_STAMP
     const long long t_loop_begin = __builtin_readcyclecounter();
 #endif
@@ -1239,8 +1257,10 @@ void conv_dma_kernel(const ConvParams p) {
 #ifdef CF_STAMP
         const long long t0 = __builtin_readcyclecounter();
 #endif
-        if (ck + 1 < nck) wait_vmcnt_le(nl);
-        else wait_vmcnt0();
+        {   // stage ck has landed once only the loads of the (up to DIST - 1) later stages are still in flight
+            const int later = nck - 1 - ck;
+            wait_vmcnt_le(nl * (later < DIST - 1 ? later : DIST - 1));
+        }
 #ifdef CF_STAMP
         const long long t1 = __builtin_readcyclecounter();
 #endif
@@ -1248,7 +1268,7 @@ void conv_dma_kernel(const ConvParams p) {
 #ifdef CF_STAMP
         const long long t2 = __builtin_readcyclecounter();
 #endif
-        if (ck + 2 < nck) issue_stage(wbuf);
+        const bool more = ck + DIST < nck;      // stage ck + DIST goes into the buffer freed by the barrier above
 #ifdef CF_STAMP
         st_wait += t1 - t0;
         st_bar += t2 - t1;
@@ -1263,7 +1283,7 @@ void conv_dma_kernel(const ConvParams p) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(sbase + fb[j][ks]);
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 4; ++s) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1274,7 +1294,16 @@ void conv_dma_kernel(const ConvParams p) {
                         acc[i][j][s] += af[i][s] * bf[j][s];
 #endif
                     }
+                // the DMA pieces of the stage being prefetched are spread evenly over the stage's MFMA groups
+                constexpr int SLOTS = (KCW / 8) * 4, PSTEP = SLOTS / NP;
+                if ((ks * 4 + s) % PSTEP == 0 && (ks * 4 + s) / PSTEP < NP) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) issue_piece(wbuf, (ks * 4 + s) / PSTEP);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
+        static_assert(NP <= (KCW / 8) * 4, "a stage's DMA pieces must fit between its MFMA groups");
         rbuf = rbuf == NBUF - 1 ? 0 : rbuf + 1;
         wbuf = wbuf == NBUF - 1 ? 0 : wbuf + 1;
     }
@@ -1356,12 +1385,12 @@ void conv_dma_kernel(const ConvParams p) {
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int WK, int KCW>
+template <int BM, int BN, int WM, int WN, int WK, int KCW, int NBUF = 3>
 static hipError_t launch_dma(const ConvParams& p, int batch, hipStream_t s) {
     if (p.a_mode != A_NHWC || p.prec != 0 || !stage_ok(p, KCW * WK)) return hipErrorInvalidValue;
     const int M = p.Ho * p.Wo;
     dim3 grid(((M + BM - 1) / BM) * ((p.cout + BN - 1) / BN) * batch);
-    hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, WK, KCW>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, WK, KCW, NBUF>), grid, dim3(256), 0, s, p);
     return hipGetLastError();
 }
 
@@ -1591,6 +1620,9 @@ const char* conv_tile_name(int tile) {
         case 28: return "conv_dma_kernel<64,128,2,2,1,16>";
         case 29: return "conv_dma_kernel<128,96,4,1,1,16>";
         case 30: return "conv_dma_kernel<128,32,4,1,1,16>";
+        case 31: return "conv_dma_kernel<32,64,1,2,2,16,nbuf4>";
+        case 32: return "conv_dma_kernel<64,64,2,2,1,16,nbuf4>";
+        case 33: return "conv_dma_kernel<128,64,2,2,1,16,nbuf4>";
         default: return "?";
     }
 }
@@ -1757,6 +1789,9 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
         case 28: return launch_dma<64, 128, 2, 2, 1, 16>(p, batch, s);
         case 29: return launch_dma<128, 96, 4, 1, 1, 16>(p, batch, s);
         case 30: return launch_dma<128, 32, 4, 1, 1, 16>(p, batch, s);
+        case 31: return launch_dma<32, 64, 1, 2, 2, 16, 4>(p, batch, s);
+        case 32: return launch_dma<64, 64, 2, 2, 1, 16, 4>(p, batch, s);
+        case 33: return launch_dma<128, 64, 2, 2, 1, 16, 4>(p, batch, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -112,6 +112,11 @@ CONV_CASES = [
     (64, 96, 3, 3, 1, 1, 1, 1, 29),
     (32, 32, 3, 3, 1, 1, 1, 0, 30),
     (64, 32, 3, 3, 2, 1, 1, 1, 30),
+    (384, 256, 1, 5, 1, 0, 2, 0, 31),  # 4-deep ring (three stages in flight)
+    (32, 64, 3, 3, 1, 1, 1, 1, 31),    # fewer stages than the ring is deep
+    (96, 96, 3, 3, 1, 1, 1, 0, 32),
+    (16, 64, 1, 1, 1, 0, 0, 0, 32),    # a single stage
+    (128, 64, 3, 3, 2, 1, 1, 1, 33),
 ]
 
 
