@@ -1744,14 +1744,14 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
             if (tile == 9 || tile == 10) tile = 20;
             else if (tile == 8 && stage_ok(p, 64)) tile = 22;
             else if (tile == 4 || tile == 12) tile = 23;
-            else if (tile == 2) tile = 26;
+            else if (tile == 2) tile = 23;      // 64x64 edges out 128x64 since the DMA pieces hide behind the MFMAs
             else if (tile == 5) tile = 28;
             else if (tile == 3) tile = 29;
             else if (tile == 6) tile = 30;
             else if (tile == 1)
                 // 128x128 once there are >= 3 full rounds of it (config 4 / 5 sizes: 125-135 TFLOP/s); with fewer
                 // workgroups the smaller tiles overlap prologue / tail better (180x240 B=8: tools/tile_sweep.sh)
-                tile = wgs128x128 >= 2304 ? 25 : ((p.cout >= 256 && p.cout % 64 == 0) ? 26 : 23);
+                tile = wgs128x128 >= 2304 ? 25 : ((p.cout >= 256 && p.cout % 128 == 0) ? 28 : 23);
         }
     }
     if (tile_used) *tile_used = tile;
