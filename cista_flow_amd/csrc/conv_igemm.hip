@@ -1,17 +1,17 @@
-// conv_igemm.hip -- implicit-GEMM convolution on the gfx950 fp32 matrix cores.
+// conv_igemm.hip -- implicit-GEMM convolution on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32
+// products and accumulation, so results differ from PyTorch only by summation order).
 //
-// One workgroup (4 waves) owns a BM x BN tile of  out[pixel][cout]  for one image.
-// K runs over (tap, cin) in chunks of 16: the A chunk (BM pixels x 16 channels of the
-// tap-shifted input, reflect/zero padded on the fly) and the B chunk (BN couts x 16) are
-// staged global -> registers -> LDS (double buffered, one barrier per chunk) and consumed
-// with v_mfma_f32_32x32x2_f32 (exact fp32 fma chain, 64 cycles each -> the staging is far
-// off the critical path; the kernel is MFMA-bound by design).
-//
-// LDS image: [row][16 k] with an 80-byte row stride.  A lane reads its row's k = 4h..4h+3
-// (h = lane>>5) of an 8-deep k group with one ds_read_b128; rows r -> 16-byte slot 5r mod 16
-// so every 16-lane group of the b128 read is bank-conflict free.  MFMA step s of a group
-// therefore multiplies k = 8g + 4h + s on both operands -- a permutation of k, which a dot
-// product does not care about.
+// One workgroup (4 waves, WAVES_M x WAVES_N x WK) owns a BM x BN tile of  out[pixel][cout]  for one image; K runs
+// over (tap, cin) in stages of 16*WK (or 32*WK) columns.  Two kernels share the tail and the tile scheduler:
+//   conv_dma_kernel    plain NHWC reads in fp32 (almost all of the flops): A / B stage tiles go straight into LDS by
+//                      buffer_load ... lds into a swizzled 3-deep ring, counted vmcnt, DMA pieces issued between the
+//                      MFMA groups (see the comment block in front of the kernel);
+//   conv_igemm_kernel  A operands that are computed while staging (fused bilinear x2 read, planar tiny-Cin gather,
+//                      fp32 activations as B, the f16 / f16x3 operand split): global -> registers -> LDS, double
+//                      buffered, rows 80 B apart so ds_read_b128 is conflict free.
+// A lane reads its row's k = 4h..4h+3 (h = lane>>5) of an 8-deep k group with one ds_read_b128; MFMA step s of a
+// group therefore multiplies k = 8g + 4h + s on both operands -- a permutation of k, which a dot product does not see.
+// The tail (bias, activations, ISTA / LSTC / LSTM / GRU updates, InstanceNorm statistics) is fused: patch_tail*.
 //
 // Reference semantics covered (each cited where it is used in cf_api.hip):
 //   nn.Conv2d(padding_mode='reflect'|'zeros', stride 1|2, kernels 1x1,3x3,7x7,1x5,5x1),
