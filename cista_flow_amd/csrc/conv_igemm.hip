@@ -993,7 +993,8 @@ static bool splitk_ok(const ConvParams& p, int wk) { return stage_ok(p, KC * wk)
 // and bank conflicts are avoided by an XOR swizzle applied on the SOURCE side (which 16-byte quad of its row a
 // lane fetches) and again when the fragments are read: slot(row, q) = row*QPR + (q ^ (row / RPB) % QPR), with
 // RPB = rows per 256-byte bank row.  Out-of-range offsets (zero padding, rows past the tile) make the DMA write
-// zeros.  Hand-off rule: wait vmcnt(loads of one stage) -> s_barrier -> issue stage k+2 -> read stage k.
+// zeros.  Hand-off rule per stage k: wait vmcnt(loads of the later stages) -> s_barrier -> ds_read + MFMA on stage k,
+// with the DMA pieces of stage k+2 (into the buffer the barrier just freed) issued between those MFMA groups.
 // ---------------------------------------------------------------------------------------------------------
 // helpers of the LDS-DMA kernel (kept out of the __global__ body: the host pass has no such builtins)
 __device__ __forceinline__ void dma16_to_lds(__amdgpu_buffer_rsrc_t rs, float* lds_dst, unsigned voff, unsigned soff) {
