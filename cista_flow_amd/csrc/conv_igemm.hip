@@ -1318,14 +1318,26 @@ void conv_dma_kernel(const ConvParams p) {
         // Split-K tail shared by all waves: every wave parks its partial 32x32 tile in patch layout, and after the barrier
         // finishes 4/WK of the patch's row groups (summing the WK partials on the way, in the order k = 0..WK-1).
         // Before, the wk > 0 waves left and one wave per sub-tile did the whole tail.
-        static_assert(WK == 1 || (TM == 1 && TN == 1), "split-K tiles hold one sub-tile per wave");
-        static_assert(WK * WMN * 32 * EPI_S <= SMEM, "partial patches must fit the stage buffers");
-        constexpr int PSTRIDE = WMN * 32 * EPI_S;
+        constexpr int NSUB = TM * TN;                         // sub-tiles per wave (1, or 3 for the 32x96 tile)
+        static_assert(WK == 1 || WK * WMN * 32 * EPI_S <= SMEM, "partial patches must fit the stage buffers");
+        constexpr int PSTRIDE = WMN * 32 * EPI_S;             // between the WK partials of a sub-tile
         float* part = smem + wk * PSTRIDE + wmn * (32 * EPI_S);
+#pragma unroll 1
+        for (int pi = 0; pi < NSUB; ++pi) {                   // one sub-tile at a time: the patches stay 18 KB
 #pragma unroll
-        for (int r = 0; r < 16; ++r) part[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_S + lr] = acc[0][0][r];
-        __syncthreads();
-        patch_tail(p, smem + wmn * (32 * EPI_S), b, m0 + wm * 32, n0 + wn * 32, lane, M, wk * (4 / WK), (wk + 1) * (4 / WK), WK, PSTRIDE);
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    if (pi == i * TN + j) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) part[((r & 3) + 8 * (r >> 2) + 4 * lh) * EPI_S + lr] = acc[i][j][r];
+                    }
+            __syncthreads();
+            const int pi_i = pi / TN, pi_j = pi - pi_i * TN;
+            patch_tail(p, smem + wmn * (32 * EPI_S), b, m0 + (wm * TM + pi_i) * 32, n0 + (wn * TN + pi_j) * 32, lane, M,
+                       wk * (4 / WK), (wk + 1) * (4 / WK), WK, PSTRIDE);
+            if (pi + 1 < NSUB) __syncthreads();               // the patches are rewritten for the next sub-tile
+        }
         return;
     }
     if (WK > 1) {
@@ -1624,6 +1636,7 @@ const char* conv_tile_name(int tile) {
         case 31: return "conv_dma_kernel<32,64,1,2,2,16,nbuf4>";
         case 32: return "conv_dma_kernel<64,64,2,2,1,16,nbuf4>";
         case 33: return "conv_dma_kernel<128,64,2,2,1,16,nbuf4>";
+        case 34: return "conv_dma_kernel<32,96,1,1,4,8>";
         default: return "?";
     }
 }
@@ -1746,6 +1759,10 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
             else if (tile == 8 && stage_ok(p, 64)) tile = 22;
             else if (tile == 4 || tile == 12) tile = 23;
             else if (tile == 2) tile = 23;      // 64x64 edges out 128x64 since the DMA pieces hide behind the MFMAs
+            // (tile 34 = 32x96 split-K covers a 96-wide cout exactly and wins in isolation, 85 vs 73 TFLOP/s on 96->96
+            // @48x64, but loses in the model -- 2.19 vs 2.11 ms for the encoder phase: 3 WGs/CU by registers and the
+            // statistics tail of three sub-tiles on one wave -- so the launcher does not pick it)
+            if (false) {}
             else if (tile == 5) tile = 28;
             else if (tile == 3) tile = 29;
             else if (tile == 6) tile = 30;
@@ -1793,6 +1810,7 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
         case 31: return launch_dma<32, 64, 1, 2, 2, 16, 4>(p, batch, s);
         case 32: return launch_dma<64, 64, 2, 2, 1, 16, 4>(p, batch, s);
         case 33: return launch_dma<128, 64, 2, 2, 1, 16, 4>(p, batch, s);
+        case 34: return launch_dma<32, 96, 1, 1, 4, 8>(p, batch, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -164,7 +164,7 @@ class Handle:
 
     def profile_read(self):
         """-> list of dicts per conv tile kind: name, ms, flops, count (index 0 = all conv launches)."""
-        n = 32
+        n = 48
         ms, fl, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_longlong * n)()
         self.check(self.lib.cf_profile_read(self.h, ms, fl, cnt, n), "cf_profile_read")
         out = []

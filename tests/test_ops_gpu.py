@@ -117,6 +117,9 @@ CONV_CASES = [
     (96, 96, 3, 3, 1, 1, 1, 0, 32),
     (16, 64, 1, 1, 1, 0, 0, 0, 32),    # a single stage
     (128, 64, 3, 3, 2, 1, 1, 1, 33),
+    (96, 96, 3, 3, 1, 1, 1, 0, 34),    # 32x96 split-K tile (three sub-tiles per wave) for the 96-channel stage
+    (64, 96, 3, 3, 2, 1, 1, 0, 34),
+    (96, 192, 1, 1, 1, 0, 0, 1, 34),
 ]
 
 
@@ -133,6 +136,8 @@ STATS_CASES = [
     (64, 64, 3, 3, 1, 1, 0, 2, 21, 37),      # register-staged kernel
     (64, 96, 3, 3, 1, 1, 0, 9, 21, 37),
     (5, 64, 7, 7, 2, 3, 2, 0, 64, 80),       # conv1 of the encoders: planar gather mode
+    (96, 96, 3, 3, 1, 1, 0, 34, 24, 32),     # 32x96 split-K tile (three sub-tiles per wave), register reduction path
+    (64, 96, 3, 3, 2, 1, 0, 0, 96, 128),     # ... as the launcher picks it for the 96-channel stage
 ]
 
 
