@@ -23,6 +23,8 @@ def main():
     for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             n = re.sub(r"^void ", "", r["Kernel_Name"]).split("(")[0].replace("cf::", "").replace(" ", "")
+            if n.startswith("conv_dma_kernel<"):       # ring depth: default 3 is not part of bench.py's names
+                n = re.sub(r",4>$", ",nbuf4>", re.sub(r",3>$", ">", n))
             acc[n][r["Counter_Name"]] += float(r["Counter_Value"])
             if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
                 cnt[n] += 1

@@ -28,6 +28,9 @@ def per_kernel(d, counter):
                 n = "%s<%s,%s,%s,%s,%s%s>" % (g[0], g[1], g[2], g[3], g[4], g[5], ",kcw32" if g[6] == "32" else "")
             elif re.match(r"void cf::conv_dma_kernel<", n):
                 n = re.sub(r"^void cf::", "", n).split("(")[0].replace(" ", "")
+                # last template argument = ring depth: 3 is the default and is not part of bench.py's names
+                n = re.sub(r",3>$", ">", n)
+                n = re.sub(r",4>$", ",nbuf4>", n)
             else:
                 n = re.sub(r"^void ", "", n).split("(")[0].replace("cf::", "")
                 n = re.sub(r"<.*>", "", n) if n.startswith("conv_smalln") else n
