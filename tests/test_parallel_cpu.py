@@ -79,3 +79,18 @@ def test_no_gpu_means_loud_failure():
     m = DCEIFlowCistaNet(a).eval()
     with pytest.raises(RuntimeError):
         m({"event_voxel": torch.zeros(1, 5, 128, 128), "rec_img0": torch.zeros(1, 1, 128, 128)}, None, {})
+
+
+def test_traffic_table_uses_the_library_kernel_names():
+    """bench.py looks the dominant kernel up in profiles/hbm_traffic.json by the name cf_conv_tile_name() returns:
+    every conv entry of the committed table must be such a name (a mismatch silently turns roofline.traffic to null)."""
+    import json
+    from cista_flow_amd import lib
+    L = lib.load()
+    names = {L.cf_conv_tile_name(t).decode() for t in range(1, 48)}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    table = json.load(open(os.path.join(root, "profiles", "hbm_traffic.json")))
+    conv = [k for k in table if k.startswith("conv_dma_kernel") or k.startswith("conv_igemm_kernel")]
+    assert conv, "no conv kernels in profiles/hbm_traffic.json"
+    for k in conv:
+        assert k in names, k
