@@ -79,6 +79,102 @@ def cpu_baseline(B, H, W, frames):
                       "(oracle/cista_oracle.py, eager PyTorch fp32, %d threads)" % (len(timed), B, H, W, cores)}
 
 
+PEAK_HBM_TBS = 8.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable with a float4 copy)
+
+
+def roofline_pass(model, step, B, dev, nprof):
+    """Separate pass: every launch of the step bracketed by HIP events on its launch stream, side streams folded into
+    the caller's stream (each kernel alone on the chip) with the SAME grids as the timed step (the two half-batch
+    CISTA chains are kept and issued back to back).  Contraction kernels are priced against the fp32 MFMA peak with
+    algorithmic flops (2*M*N*K, un-padded K), the rest against the HBM peak with algorithmic bytes (each input read
+    once, each output written once)."""
+    h = model._be().get(B, dev)
+    h.profile_enable(True)
+    with torch.no_grad():
+        for _ in range(nprof):
+            step(gather=False)       # rank 0 only: no collective may be issued in this leg
+    torch.cuda.synchronize()
+    recs = h.profile_read()
+    rows = h.profile_rows()
+    h.profile_enable(False)
+    if os.environ.get("CF_LAYER_REPORT"):
+        with open(os.environ["CF_LAYER_REPORT"], "w") as f:
+            f.write("# per-launch-site timing over %d steps (HIP events on the launch stream, kernels serialised, same grids as the timed step)\n" % nprof
+                    + h.profile_report())
+        with open(os.environ["CF_LAYER_REPORT"] + ".json", "w") as f:
+            json.dump({"steps": nprof, "rows": rows}, f)
+
+    def agg(sel):
+        out = {}
+        for r in rows:
+            if not sel(r):
+                continue
+            a = out.setdefault(r["kernel"], {"ms": 0.0, "work": 0.0, "launches": 0})
+            a["ms"] += r["ms"]; a["work"] += r["work"]; a["launches"] += r["launches"]
+        return out
+
+    mf = agg(lambda r: r["class"] == "mfma")
+    hb = agg(lambda r: r["class"] == "hbm")
+    dom_name = max(mf, key=lambda k: mf[k]["ms"])
+    dom = mf[dom_name]
+    ach = dom["work"] / (dom["ms"] * 1e-3) / 1e12
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            ent = tj.get(dom_name) or tj.get(dom_name.replace(",3>", ">"))
+            if ent:
+                traffic = {"bytes_per_launch": ent.get("bytes_per_launch"), "static": True, "source": "profiles/hbm_traffic.json",
+                           "collected": tj.get("_meta", {}).get("collected", "round 1 build (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH doubled per the guide)"),
+                           "note": "NOT measured by this run: PMC counters need their own rocprofv3 passes (tools/make_profiles.sh)"}
+        except Exception:
+            traffic = None
+    mf_ms = sum(v["ms"] for v in mf.values())
+    mf_work = sum(v["work"] for v in mf.values())
+    hb_ms = sum(v["ms"] for v in hb.values())
+    hb_work = sum(v["work"] for v in hb.values())
+
+    def cls(sel):
+        m_ms = sum(r["ms"] for r in rows if sel(r) and r["class"] == "mfma")
+        m_w = sum(r["work"] for r in rows if sel(r) and r["class"] == "mfma")
+        b_ms = sum(r["ms"] for r in rows if sel(r) and r["class"] == "hbm")
+        b_w = sum(r["work"] for r in rows if sel(r) and r["class"] == "hbm")
+        tot = m_ms + b_ms
+        mfr = (m_w / (m_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if m_ms else None
+        hfr = (b_w / (b_ms * 1e-3) / 1e12 / PEAK_HBM_TBS) if b_ms else None
+        comb = ((m_ms * (mfr or 0) + b_ms * (hfr or 0)) / tot) if tot else None
+        return {"ms_per_step": round(tot / nprof, 3), "mfma_ms_per_step": round(m_ms / nprof, 3), "hbm_ms_per_step": round(b_ms / nprof, 3),
+                "mfma_frac": None if mfr is None else round(mfr, 4), "hbm_frac": None if hfr is None else round(hfr, 4),
+                "time_weighted_frac": None if comb is None else round(comb, 4)}
+
+    return {
+        "bound": "mfma", "kernel": dom_name, "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+        "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+        "note": "separate pass, HIP events on the launch stream, side streams folded into one stream (each kernel alone on the "
+                "chip), SAME launch grids as the timed step (half-batch CISTA chains kept, issued back to back)",
+        "launches_per_step": dom["launches"] / nprof,
+        "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
+        "flops_per_launch": dom["work"] / dom["launches"],
+        "all_conv": {"achieved": round(mf_work / (mf_ms * 1e-3) / 1e12, 2), "ms_per_step": round(mf_ms / nprof, 3),
+                     "launches_per_step": sum(v["launches"] for v in mf.values()) / nprof, "gflop_per_step": round(mf_work / nprof / 1e9, 2)},
+        "by_kernel": {k: {"ms_per_step": round(v["ms"] / nprof, 3), "tflops": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 2),
+                          "launches_per_step": v["launches"] / nprof} for k, v in sorted(mf.items(), key=lambda kv: -kv[1]["ms"])},
+        # the HBM class: algorithmic bytes / HIP-event time against the 8 TB/s spec peak, per kernel and time-weighted
+        "hbm": {"peak": PEAK_HBM_TBS, "unit": "TB/s", "achieved": round(hb_work / (hb_ms * 1e-3) / 1e12, 3) if hb_ms else None,
+                "frac": round(hb_work / (hb_ms * 1e-3) / 1e12 / PEAK_HBM_TBS, 4) if hb_ms else None,
+                "ms_per_step": round(hb_ms / nprof, 3), "launches_per_step": sum(v["launches"] for v in hb.values()) / nprof,
+                "by_kernel": {k: {"ms_per_step": round(v["ms"] / nprof, 4), "avg_launch_us": round(v["ms"] * 1e3 / v["launches"], 2),
+                                  "mbytes_per_launch": round(v["work"] / v["launches"] / 1e6, 3),
+                                  "tbs": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 3),
+                                  "frac": round(v["work"] / (v["ms"] * 1e-3) / 1e12 / PEAK_HBM_TBS, 4),
+                                  "launches_per_step": v["launches"] / nprof} for k, v in sorted(hb.items(), key=lambda kv: -kv[1]["ms"])}},
+        # north-star step "CISTA unrolled iterations + flow warp": both classes and their time-weighted combination
+        "cista_warp_step": cls(lambda r: r["tag"].startswith("cista.") or r["tag"].startswith("warp.")),
+        "whole_step": cls(lambda r: True),
+    }
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -115,6 +211,10 @@ def main():
     model = model.to(dev)
     if a.model != "idnet":
         model.event_flownet.return_flow_preds = True  # like the reference: every iteration's up-flow is produced
+    if a.model == "eraft":
+        # the driver loop below carries `event_voxel_old = previous event_voxel` as the SAME tensor object, never written
+        # in between (test_with_flow.py:144-149): the aliasing contract the fnet feature reuse needs
+        model.reuse_prev_features = True
     R = 8
     evs = [wu.synth_events(B, 5, H, W, 1234 + 100 * rank + i).to(dev) for i in range(R)]
     side = torch.cuda.Stream(device=dev) if world > 1 else None
@@ -166,42 +266,7 @@ def main():
 
     roofline = None
     if not a.no_roofline and rank == 0:
-        h = model._be().get(B, dev)
-        h.profile_enable(True)
-        nprof = min(a.steps, 10)
-        with torch.no_grad():
-            for _ in range(nprof):
-                step(gather=False)       # rank 0 only: no collective may be issued in this leg
-        torch.cuda.synchronize()
-        recs = h.profile_read()
-        h.profile_enable(False)
-        if os.environ.get("CF_LAYER_REPORT"):
-            with open(os.environ["CF_LAYER_REPORT"], "w") as f:
-                f.write("# per-layer conv timing over %d steps (HIP events)\n" % nprof + h.profile_report())
-        tiles = [r for r in recs[1:] if r["count"] > 0]
-        dom = max(tiles, key=lambda r: r["ms"])
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(dom["name"], {}).get("bytes_per_launch")
-            except Exception:
-                traffic = None
-        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-        roofline = {
-            "bound": "mfma", "kernel": dom["name"], "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-            "note": "measured in a separate pass with the library's side streams serialised (each kernel alone on the chip)",
-            "launches_per_step": dom["count"] / nprof,
-            "avg_launch_us": round(dom["ms"] * 1e3 / dom["count"], 2),
-            "flops_per_launch": dom["flops"] / dom["count"],
-            "all_conv": {"achieved": round(recs[0]["flops"] / (recs[0]["ms"] * 1e-3) / 1e12, 2),
-                         "ms_per_step": round(recs[0]["ms"] / nprof, 3), "launches_per_step": recs[0]["count"] / nprof,
-                         "gflop_per_step": round(recs[0]["flops"] / nprof / 1e9, 2)},
-            "by_kernel": {r["name"]: {"ms_per_step": round(r["ms"] / nprof, 3),
-                                      "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2),
-                                      "launches_per_step": r["count"] / nprof} for r in tiles},
-        }
+        roofline = roofline_pass(model, step, B, dev, min(a.steps, 10))
 
     alt = None
     if not a.no_alt and os.environ.get("CF_PRECISION") is None:

@@ -83,6 +83,6 @@ class DCEIFlow(nn.Module):
         flow_low = torch.empty((B, 2, h8, w8), dtype=torch.float32, device=dev)
         preds = torch.empty((iters, B, 2, Hp, Wp), dtype=torch.float32, device=dev) if self.return_flow_preds else None
         h.check(h.lib.cf_flow_forward(h.h, _lib.ptr(ev), _lib.ptr(im), _lib.ptr(flow_init), _lib.ptr(flow_final),
-                                      _lib.ptr(flow_low), _lib.ptr(preds), _lib.current_stream_ptr()), "cf_flow_forward")
+                                      _lib.ptr(flow_low), _lib.ptr(preds), _lib.current_stream_ptr(dev)), "cf_flow_forward")
         return dict(flow_preds=[preds[i] for i in range(iters)] if preds is not None else [],
                     flow_init=flow_low, flow_final=flow_final)

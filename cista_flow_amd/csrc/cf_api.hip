@@ -114,11 +114,13 @@ struct cf_handle {
     static constexpr int CORR_LD = 336;   // 4*81 = 324 correlation channels padded to a multiple of 16
 
     // per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
-    struct ProfRec { int tile; double flops; hipEvent_t a, b; const char* tag; };
+    // cls: 0 = contraction (MFMA roofline, `work` = algorithmic flops), 1 = HBM class (`work` = algorithmic bytes)
+    struct ProfRec { int tile; int cls; double work; hipEvent_t a, b; const char* tag; const char* kernel; long threads; };
     const char* tag = "";
-    std::string prof_report;
+    std::string prof_report, prof_json;
     bool prof = false;
     bool serial = false;   // measurement mode: no side-stream concurrency
+    bool serial_env = false;
     // batch window applied by run_conv (images [win_b0, win_b0 + win_n) of every tensor); win_n == 0: whole batch
     int win_b0 = 0, win_n = 0;
     // CF_PHASES=1 (tuning aid): HIP events on the caller's stream at the phase boundaries of cf_step, averaged
@@ -216,15 +218,81 @@ static hipError_t run_conv(cf_handle* h, const ConvParams& p_in, int batch, hipS
     cf_handle::ProfRec r;
     r.a = h->prof_event();
     r.b = h->prof_event();
-    r.flops = 2.0 * (double)p.Ho * p.Wo * p.cout * (double)p.k_real * batch;
+    r.work = 2.0 * (double)p.Ho * p.Wo * p.cout * (double)p.k_real * batch;
+    r.cls = 0;
     r.tile = 0;
     r.tag = p.tag ? p.tag : h->tag;
     (void)hipEventRecord(r.a, st);
     hipError_t e = launch_conv(p, batch, st, tile, &r.tile);
     (void)hipEventRecord(r.b, st);
+    if (r.tile == 7) {      // 1-2 output channels on the vector ALUs: reads the input once, HBM class
+        r.cls = 1;
+        r.work = 4.0 * batch * ((double)p.Hin * p.Win * p.cin_pad + (double)p.Ho * p.Wo * p.cout);
+    }
+    r.kernel = g_last_launch.kernel;
+    r.threads = g_last_launch.threads;
     h->prof_recs.push_back(r);
     return e;
 }
+
+// HIP-event bracket around one launch of an HBM-class kernel (bytes = ALGORITHMIC bytes of that launch: every
+// input read once, every output written once -- SURVEY 8d); inert unless cf_profile_enable is on
+namespace {
+struct ProfScope {
+    cf_handle* h;
+    hipStream_t st;
+    cf_handle::ProfRec r;
+    bool on;
+    ProfScope(cf_handle* h_, hipStream_t st_, const char* tag, double bytes) : h(h_), st(st_), on(h_ && h_->prof) {
+        if (!on) return;
+        r.a = h->prof_event();
+        r.b = h->prof_event();
+        r.work = bytes;
+        r.cls = 1;
+        r.tile = 0;
+        r.tag = tag;
+        (void)hipEventRecord(r.a, st);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(r.b, st);
+        r.kernel = g_last_launch.kernel;
+        r.threads = g_last_launch.threads;
+        h->prof_recs.push_back(r);
+    }
+};
+// the C entry points switch to the handle's device and restore the caller's on every exit path
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess; else prev = -1;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+// A graph that forks work onto the library's side streams joins every one of them back into the caller's stream
+// on EVERY exit path: after an early error return nothing may still be running on a side stream when the caller
+// frees its tensors or starts the next call.
+struct JoinGuard {
+    cf_handle* h;
+    hipStream_t st;
+    bool armed = true;
+    JoinGuard(cf_handle* h_, hipStream_t st_) : h(h_), st(st_) {}
+    void disarm() { armed = false; }      // normal exit: the graph has already joined what it forked
+    ~JoinGuard() {
+        if (!armed) return;
+        for (int i = 0; i < 3; ++i) {
+            if (!h->aux[i] || h->aux[i] == st) continue;
+            if (hipEventRecord(h->ev_join[i], h->aux[i]) == hipSuccess) (void)hipStreamWaitEvent(st, h->ev_join[i], 0);
+        }
+        (void)hipGetLastError();
+    }
+};
+}  // namespace
+#define CF_CAT2(a, b) a##b
+#define CF_CAT(a, b) CF_CAT2(a, b)
+#define PROF(h, st, tag, bytes) ProfScope CF_CAT(_ps_, __LINE__)((h), (st), (tag), (double)(bytes))
 
 // ---------------------------------------------------------------------------------------------
 // workspace layout
@@ -408,6 +476,11 @@ static int pack_conv(cf_handle* h, const std::string& key, const std::string& pr
         pc.cin = cin_eff; pc.KH = KH; pc.KW = KW; pc.gather = gather;
         pc.cin_pad = gather ? 0 : round_up(cin_eff, 16);
         pc.Ktot = gather ? round_up(KH * KW * cin_eff, 16) : KH * KW * pc.cin_pad;
+        // the planar small-Cin gather conv keeps its whole k -> (ky, kx, c) table in LDS: K = KH*KW*Cin <= 256, i.e.
+        // at most 5 bins through a 7x7 stem and 28 through We (conv_igemm.hip: A_GATHER)
+        if (gather && pc.Ktot > 256)
+            return h->fail(CF_ERR_UNSUPPORTED, prefix + ": KH*KW*Cin = " + std::to_string(KH * KW * cin_eff) +
+                                                   " exceeds the 256-column limit of the planar gather convolution (num_bins too large for this kernel size)");
         pc.cout = total_rows > 0 ? total_rows : Cout;
         pc.rows = round_up(pc.cout, 128);
         const size_t wbytes = (size_t)pc.rows * pc.Ktot * sizeof(float);
@@ -477,7 +550,8 @@ extern "C" int cf_finalize_weights(cf_handle* h, void* stream) {
     if (!h) return CF_ERR_ARG;
     h->fmap2_valid = false;       // cached ERAFT feature maps belong to the old weights
     hipStream_t st = static_cast<hipStream_t>(stream);
-    CF_HIP(h, hipSetDevice(h->cfg.device));
+    DeviceGuard dg(h->cfg.device);
+    if (!dg.ok) return h->fail(CF_ERR_HIP, "hipSetDevice failed");
     for (void* p : h->owned) (void)hipFree(p);
     h->owned.clear();
     h->conv.clear();
@@ -668,7 +742,8 @@ extern "C" int cf_create(cf_handle** out, const cf_config* cfg) {
         delete h;
         return bad("cf_create: padded image must be >= 128x128 (4th correlation pyramid level >= 2x2)");
     }
-    if (hipSetDevice(cfg->device) != hipSuccess) {
+    DeviceGuard dg(cfg->device);
+    if (!dg.ok) {
         delete h;
         g_create_error = "cf_create: hipSetDevice failed (no GPU?)";
         return CF_ERR_HIP;
@@ -689,6 +764,10 @@ extern "C" int cf_create(cf_handle** out, const cf_config* cfg) {
         return CF_ERR_HIP;
     }
     bool ok = true;
+    // CF_SERIAL=1: no side-stream concurrency (every kernel alone on the chip) without the HIP-event bracketing --
+    // the mode a rocprofv3 --kernel-trace of the timed loop is taken in (tools/make_profiles.sh)
+    if (const char* e = getenv("CF_SERIAL")) h->serial_env = atoi(e) != 0;
+    h->serial = h->serial_env;
     if (const char* e = getenv("CF_PHASES")) {
         h->phases = atoi(e) != 0;
         for (int i = 0; h->phases && i < 4; ++i) ok = ok && hipEventCreate(&h->ph_ev[i]) == hipSuccess;
@@ -718,7 +797,7 @@ extern "C" int cf_create(cf_handle** out, const cf_config* cfg) {
 
 extern "C" void cf_destroy(cf_handle* h) {
     if (!h) return;
-    (void)hipSetDevice(h->cfg.device);
+    DeviceGuard dg(h->cfg.device);
     for (void* p : h->owned) (void)hipFree(p);
     if (h->arena_mem) (void)hipFree(h->arena_mem);
     for (int i = 0; i < 3; ++i) {
@@ -749,43 +828,60 @@ extern "C" size_t cf_workspace_bytes(const cf_handle* h) { return h ? h->arena.c
 extern "C" int cf_profile_enable(cf_handle* h, int on) {
     if (!h) return CF_ERR_ARG;
     h->prof = on != 0;
-    h->serial = on != 0;
+    h->serial = on != 0 || h->serial_env;
     return CF_OK;
 }
 
 // Synchronises the recorded events, then for tile kind t = 1..n-1 (conv_igemm.hip: conv_tile_name) accumulates
-// ms[t] (sum of launch durations), flops[t] (sum of algorithmic flops), count[t]; index 0 = totals.
+// ms[t] (sum of launch durations), flops[t] (sum of algorithmic flops), count[t]; index 0 = totals over the
+// contraction class.  Also builds the per-layer text table (cf_profile_report) and the JSON table over BOTH classes
+// (cf_profile_report_json): one row per (kernel symbol, grid, layer tag).
 extern "C" int cf_profile_read(cf_handle* h, double* ms, double* flops, long long* count, int n) {
     if (!h || !ms || !flops || !count || n < 16) return CF_ERR_ARG;
     for (int i = 0; i < n; ++i) { ms[i] = 0; flops[i] = 0; count[i] = 0; }
-    struct Agg { double ms = 0, flops = 0; long cnt = 0; int tile = 0; };
+    struct Agg { double ms = 0, work = 0; long cnt = 0; int tile = 0, cls = 0; std::string kernel, tag; long threads = 0; };
     std::map<std::string, Agg> agg;
     for (auto& r : h->prof_recs) {
         float t = 0.f;
         if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&t, r.a, r.b) != hipSuccess)
             return h->fail(CF_ERR_HIP, "cf_profile_read: event query failed");
-        const int k = (r.tile >= 1 && r.tile < n) ? r.tile : 0;
-        if (k) { ms[k] += t; flops[k] += r.flops; count[k] += 1; }
-        ms[0] += t; flops[0] += r.flops; count[0] += 1;
-        Agg& a = agg[r.tag ? r.tag : ""];
-        a.ms += t; a.flops += r.flops; a.cnt += 1; a.tile = r.tile;
+        if (r.cls == 0) {
+            const int k = (r.tile >= 1 && r.tile < n) ? r.tile : 0;
+            if (k) { ms[k] += t; flops[k] += r.work; count[k] += 1; }
+            ms[0] += t; flops[0] += r.work; count[0] += 1;
+        }
+        const std::string key = std::string(r.tag ? r.tag : "") + "|" + (r.kernel ? r.kernel : "") + "|" + std::to_string(r.threads);
+        Agg& a = agg[key];
+        a.ms += t; a.work += r.work; a.cnt += 1; a.tile = r.tile; a.cls = r.cls;
+        a.kernel = r.kernel ? r.kernel : ""; a.tag = r.tag ? r.tag : ""; a.threads = r.threads;
         h->prof_pool.push_back(r.a);
         h->prof_pool.push_back(r.b);
     }
     h->prof_recs.clear();
     h->prof_report.clear();
-    char line[256];
+    h->prof_json = "[";
+    char line[512];
+    bool first = true;
     for (auto& kv : agg) {
-        snprintf(line, sizeof(line), "%-28s tile %d launches %6ld  ms %9.3f  avg_us %8.2f  TFLOP/s %7.2f\n", kv.first.c_str(),
-                 kv.second.tile, kv.second.cnt, kv.second.ms, kv.second.ms * 1e3 / kv.second.cnt,
-                 kv.second.flops / (kv.second.ms * 1e-3) / 1e12);
+        const Agg& a = kv.second;
+        const double rate = a.work / (a.ms * 1e-3) / 1e12;       // TFLOP/s or TB/s
+        snprintf(line, sizeof(line), "%-44s %-40s grid %9ld launches %6ld  ms %9.3f  avg_us %8.2f  %s %8.3f\n", a.tag.c_str(),
+                 a.kernel.c_str(), a.threads, a.cnt, a.ms, a.ms * 1e3 / a.cnt, a.cls == 0 ? "TFLOP/s" : "TB/s   ", rate);
         h->prof_report += line;
+        snprintf(line, sizeof(line), "%s{\"tag\":\"%s\",\"kernel\":\"%s\",\"grid\":%ld,\"class\":\"%s\",\"launches\":%ld,\"ms\":%.6f,\"work\":%.6e}",
+                 first ? "" : ",", a.tag.c_str(), a.kernel.c_str(), a.threads, a.cls == 0 ? "mfma" : "hbm", a.cnt, a.ms, a.work);
+        h->prof_json += line;
+        first = false;
     }
+    h->prof_json += "]";
     return CF_OK;
 }
 
-// per-layer table of the last cf_profile_read (layer tag, tile kind, launches, time, achieved TFLOP/s)
+// per-layer table of the last cf_profile_read (layer tag, kernel, grid, launches, time, achieved TFLOP/s or TB/s)
 extern "C" const char* cf_profile_report(const cf_handle* h) { return h ? h->prof_report.c_str() : ""; }
+// the same rows as JSON: [{tag, kernel, grid (work-items = rocprofv3 Grid_Size), class "mfma"|"hbm", launches, ms (sum),
+// work (sum of algorithmic flops or bytes)}]
+extern "C" const char* cf_profile_report_json(const cf_handle* h) { return h ? h->prof_json.c_str() : "[]"; }
 
 extern "C" const char* cf_conv_tile_name(int tile) { return conv_tile_name(tile); }
 
@@ -838,11 +934,16 @@ static int cista_forward(cf_handle* h, const float* ev, const float* img, const 
     // drops out of the many-rounds regime the 128x128 tile needs); four chains always lose.
     int nch = cista_chains_env();
     if (nch == 0) nch = ((h->B % 2) == 0 && (long)h->h * h->w * (h->B / 2) <= 100000) ? 2 : 1;
-    if ((nch != 2 && nch != 4) || h->serial || (h->B % nch) != 0)
+    if ((nch != 2 && nch != 4) || (h->B % nch) != 0)
         return cista_chain(h, ev, img, c_prev, z_prev, h_prev, cc_prev, I_out, c_out, z_out, h_out, cc_out, st);
-    hipStream_t cs[4] = {st, h->aux[0], h->aux[1], h->aux[2]};
-    CF_HIP(h, hipEventRecord(h->ev_fork, st));
-    for (int g = 1; g < nch; ++g) CF_HIP(h, hipStreamWaitEvent(cs[g], h->ev_fork, 0));
+    // measurement mode keeps the part-batch launches (same grids as the timed step) but issues the chains back to
+    // back on the caller's stream, so that every launch runs alone on the chip
+    hipStream_t cs[4] = {st, h->serial ? st : h->aux[0], h->serial ? st : h->aux[1], h->serial ? st : h->aux[2]};
+    JoinGuard jg(h, st);
+    if (!h->serial) {
+        CF_HIP(h, hipEventRecord(h->ev_fork, st));
+        for (int g = 1; g < nch; ++g) CF_HIP(h, hipStreamWaitEvent(cs[g], h->ev_fork, 0));
+    }
     int rc = CF_OK;
     for (int g = 0; g < nch && rc == CF_OK; ++g) {
         h->win_b0 = g * (h->B / nch);
@@ -852,10 +953,13 @@ static int cista_forward(cf_handle* h, const float* ev, const float* img, const 
     h->win_b0 = 0;
     h->win_n = 0;
     if (rc != CF_OK) return rc;
-    for (int g = 1; g < nch; ++g) {
-        CF_HIP(h, hipEventRecord(h->ev_join[g - 1], cs[g]));
-        CF_HIP(h, hipStreamWaitEvent(st, h->ev_join[g - 1], 0));
+    if (!h->serial) {
+        for (int g = 1; g < nch; ++g) {
+            CF_HIP(h, hipEventRecord(h->ev_join[g - 1], cs[g]));
+            CF_HIP(h, hipStreamWaitEvent(st, h->ev_join[g - 1], 0));
+        }
     }
+    jg.disarm();
     return CF_OK;
 }
 
@@ -931,7 +1035,7 @@ static int cista_chain(cf_handle* h, const float* ev, const float* img, const fl
             // (~105 TFLOP/s) instead of the register-staged fused read (~85)
             const long b0 = h->win_n > 0 ? h->win_b0 : 0;
             const int bn = h->win_n > 0 ? h->win_n : B;
-            CF_HIP(h, launch_upsample2x_nhwc(h_out + b0 * hw * bc, bc, hw * bc, h->upin + b0 * HW * bc, bc, HW * bc, bn, hh, ww, bc, st));
+            { PROF(h, st, "cista.upsample2x", 4.0 * bn * bc * (hw + HW)); CF_HIP(h, launch_upsample2x_nhwc(h_out + b0 * hw * bc, bc, hw * bc, h->upin + b0 * HW * bc, bc, HW * bc, bn, hh, ww, bc, st)); }
             ConvParams u = nhwc_conv(h->conv["cista.upsamp"], {{h->upin, bc, bc, HW * bc}}, H, W, H, W, 1, 1, 1, 1, h->up, bc,
                                      HW * bc, EPI_RELU);
             CF_HIP(h, run_conv(h, u, B, st));
@@ -958,7 +1062,8 @@ extern "C" int cf_cista_forward(cf_handle* h, const float* ev, const float* img,
     if (!h->finalized || !h->has_cista) return h->fail(CF_ERR_STATE, "cf_cista_forward: CISTA weights not finalised");
     if (!ev || !img || !I_out || !c_out || !z_out || !h_out || !cc_out) return h->fail(CF_ERR_ARG, "cf_cista_forward: null pointer");
     if ((h_prev == nullptr) != (cc_prev == nullptr)) return h->fail(CF_ERR_ARG, "cf_cista_forward: h_prev/cc_prev must come together");
-    CF_HIP(h, hipSetDevice(h->cfg.device));
+    DeviceGuard dg(h->cfg.device);
+    if (!dg.ok) return h->fail(CF_ERR_HIP, "hipSetDevice failed");
     return cista_forward(h, ev, img, c_prev, z_prev, h_prev, cc_prev, I_out, c_out, z_out, h_out, cc_out,
                          static_cast<hipStream_t>(stream));
 }
@@ -982,9 +1087,10 @@ static int encoder_forward(cf_handle* h, const std::string& pre, bool bn, const 
         if (!bn) p.st_partial = sc.partial;      // InstanceNorm statistics ride on the conv epilogue
         CF_HIP(h, run_conv(h, p, B, st));
         if (!bn) {
-            CF_HIP(h, launch_inorm_final(sc.partial, (Hc * Wc + 31) / 32, B, Hc * Wc, 64, eps, sc.stats, st));
-            CF_HIP(h, launch_inorm_apply(Bf, 64, (long)Hc * Wc * 64, sc.stats, nullptr, 0, 0, nullptr, A, 64,
-                                         (long)Hc * Wc * 64, B, Hc * Wc, 64, st));
+            { PROF(h, st, "enc.inorm_final", 16.0 * B * ((Hc * Wc + 31) / 32) * 64); CF_HIP(h, launch_inorm_final(sc.partial, (Hc * Wc + 31) / 32, B, Hc * Wc, 64, eps, sc.stats, st)); }
+            { PROF(h, st, "enc.inorm_apply", 8.0 * B * Hc * Wc * 64);
+              CF_HIP(h, launch_inorm_apply(Bf, 64, (long)Hc * Wc * 64, sc.stats, nullptr, 0, 0, nullptr, A, 64,
+                                           (long)Hc * Wc * 64, B, Hc * Wc, 64, st)); }
         }
     }
     // x lives in A; scratch Bf, Cf, Df
@@ -1017,12 +1123,12 @@ static int encoder_forward(cf_handle* h, const std::string& pre, bool bn, const 
                 ConvParams c1 = nhwc_conv(K(b + ".conv1"), {{A, Cx, Cx, ibs}}, Hc, Wc, Ho, Wo, stride, 1, 1, 0, Bf, Cd, obs, EPI_NONE);
                 c1.st_partial = sc.partial;
                 CF_HIP(h, run_conv(h, c1, B, st));
-                CF_HIP(h, launch_inorm_final(sc.partial, (Ho * Wo + 31) / 32, B, Ho * Wo, Cd, eps, sc.stats, st));
-                CF_HIP(h, launch_inorm_apply(Bf, Cd, obs, sc.stats, nullptr, 0, 0, nullptr, Cf, Cd, obs, B, Ho * Wo, Cd, st));
+                { PROF(h, st, "enc.inorm_final", 16.0 * B * ((Ho * Wo + 31) / 32) * Cd); CF_HIP(h, launch_inorm_final(sc.partial, (Ho * Wo + 31) / 32, B, Ho * Wo, Cd, eps, sc.stats, st)); }
+                { PROF(h, st, "enc.inorm_apply", 8.0 * B * Ho * Wo * Cd); CF_HIP(h, launch_inorm_apply(Bf, Cd, obs, sc.stats, nullptr, 0, 0, nullptr, Cf, Cd, obs, B, Ho * Wo, Cd, st)); }
                 ConvParams c2 = nhwc_conv(K(b + ".conv2"), {{Cf, Cd, Cd, obs}}, Ho, Wo, Ho, Wo, 1, 1, 1, 0, Bf, Cd, obs, EPI_NONE);
                 c2.st_partial = sc.partial;
                 CF_HIP(h, run_conv(h, c2, B, st));
-                CF_HIP(h, launch_inorm_final(sc.partial, (Ho * Wo + 31) / 32, B, Ho * Wo, Cd, eps, sc.stats, st));
+                { PROF(h, st, "enc.inorm_final", 16.0 * B * ((Ho * Wo + 31) / 32) * Cd); CF_HIP(h, launch_inorm_final(sc.partial, (Ho * Wo + 31) / 32, B, Ho * Wo, Cd, eps, sc.stats, st)); }
                 const float* res = A;
                 int res_ld = Cx;
                 long res_bs = ibs;
@@ -1031,10 +1137,10 @@ static int encoder_forward(cf_handle* h, const std::string& pre, bool bn, const 
                     ConvParams ds = nhwc_conv(K(b + ".downsample.0"), {{A, Cx, Cx, ibs}}, Hc, Wc, Ho, Wo, stride, 0, 0, 0, Cf, Cd, obs, EPI_NONE);
                     ds.st_partial = sc.partial;
                     CF_HIP(h, run_conv(h, ds, B, st));
-                    CF_HIP(h, launch_inorm_final(sc.partial, (Ho * Wo + 31) / 32, B, Ho * Wo, Cd, eps, sc.stats2, st));
+                    { PROF(h, st, "enc.inorm_final", 16.0 * B * ((Ho * Wo + 31) / 32) * Cd); CF_HIP(h, launch_inorm_final(sc.partial, (Ho * Wo + 31) / 32, B, Ho * Wo, Cd, eps, sc.stats2, st)); }
                     res = Cf; res_ld = Cd; res_bs = obs; res_stats = sc.stats2;
                 }
-                CF_HIP(h, launch_inorm_apply(Bf, Cd, obs, sc.stats, res, res_ld, res_bs, res_stats, Df, Cd, obs, B, Ho * Wo, Cd, st));
+                { PROF(h, st, "enc.inorm_apply_res", 12.0 * B * Ho * Wo * Cd); CF_HIP(h, launch_inorm_apply(Bf, Cd, obs, sc.stats, res, res_ld, res_bs, res_stats, Df, Cd, obs, B, Ho * Wo, Cd, st)); }
                 std::swap(A, Df);
             }
             Hc = Ho; Wc = Wo; Cx = Cd;
@@ -1074,6 +1180,7 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
     // that every kernel's HIP-event duration is that kernel alone on the chip
     hipStream_t sx0 = h->serial ? st : h->aux[0];
     hipStream_t sx1 = h->serial ? st : h->aux[1];
+    JoinGuard jg(h, st);
     // encoders: emap = enet(pad(ev)); fmap1 = fnet(pad(2*I-1)); cnet(pad(2*I-1)) -> net, inp.
     // The three encoders are independent and individually too small to fill 256 CUs at 1/4 and 1/8
     // resolution, so they run concurrently: enet on the caller's stream, fnet / cnet on the side streams.
@@ -1140,10 +1247,10 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
         p.tag = "corr.allpairs";
         CF_HIP(h, run_conv(h, p, B, st));
         for (int l = 1; l < 4; ++l)
-            CF_HIP(h, launch_corr_pool(h->corr[l - 1], h->corr[l], (long)B * N, h->clh[l - 1], h->clw[l - 1], st));
+            { PROF(h, st, "corr.pool", 5.0 * B * N * h->clh[l - 1] * h->clw[l - 1]); CF_HIP(h, launch_corr_pool(h->corr[l - 1], h->corr[l], (long)B * N, h->clh[l - 1], h->clw[l - 1], st)); }
     }
     h->phase_mark(1, st);
-    CF_HIP(h, launch_coords_init(h->coords1, flow_init, B, h8, w8, st));
+    { PROF(h, st, "coords_init", 8.0 * B * N * (flow_init ? 2 : 1)); CF_HIP(h, launch_coords_init(h->coords1, flow_init, B, h8, w8, st)); }
     if (flag) CF_HIP(h, hipMemsetAsync(flag, 0, sizeof(int), st));
     const int iters = h->cfg.iters;
     // The up-sampled flow of the intermediate iterations (flow_preds) is nobody's input: it is produced on side stream
@@ -1157,7 +1264,7 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
         lp.coords1 = h->coords1; lp.out = h->corrfeat; lp.out_ld = cf_handle::CORR_LD;
         lp.motion = h->motion; lp.mo_ld = 128; lp.mo_off = 126;
         lp.B = B; lp.h8 = h8; lp.w8 = w8; lp.radius = 4; lp.nlevels = 4;
-        CF_HIP(h, launch_corr_lookup(lp, st));
+        { PROF(h, st, "corr.lookup", 4.0 * B * N * (4 * 324 + cf_handle::CORR_LD)); CF_HIP(h, launch_corr_lookup(lp, st)); }
         // BasicMotionEncoder  with_event_updater.py:102-112.  The flow branch (convf1 -> convf2) only needs
         // coords1, so it runs on a side stream next to lookup -> convc1 -> convc2.
         CF_HIP(h, hipEventRecord(h->ev_fork, st));
@@ -1224,8 +1331,9 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
         if (!eraft) {
             // upflow8 + unpad   DCEIFlow.py:222-227
             if (last || up)
-                CF_HIP(h, launch_upflow(h->coords1, B, h8, w8, 8, up, last ? flow_final : nullptr, h->H, h->W, h->padH, h->padW,
-                                        last ? flag : nullptr, su));
+                { PROF(h, su, "upflow8", 8.0 * B * (N + (up ? (double)h->Hp * h->Wp : 0.0) + (last ? (double)h->H * h->W : 0.0)));
+                  CF_HIP(h, launch_upflow(h->coords1, B, h8, w8, 8, up, last ? flow_final : nullptr, h->H, h->W, h->padH, h->padW,
+                                          last ? flag : nullptr, su)); }
         } else if (last || up) {
             // mask = .25 * mask(net) (update.py:105) + learned convex up-sampling (eraft.py:77-88).  The reference
             // evaluates this on all 12 iterations; only iterations whose up-flow is requested are computed here.
@@ -1234,8 +1342,9 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
             ConvParams m2 = nhwc_conv(h->conv["mask.2"], {{h->mask1, 256, 256, N * 256}}, h8, w8, h8, w8, 1, 0, 0, 0, h->maskbuf, 576, N * 576, EPI_BIAS_SCALE);
             m2.scale = 0.25f;
             CF_HIP(h, run_conv(h, m2, B, su));
-            CF_HIP(h, launch_convex_upsample(h->coords1, 0, h->maskbuf, 576, B, h8, w8, up, last ? flow_final : nullptr, h->H,
-                                             h->W, h->padH, h->padW, last ? flag : nullptr, nullptr, nullptr, su));
+            { PROF(h, su, "convex_upsample", 4.0 * B * (578.0 * N + 2.0 * ((up ? (double)h->Hp * h->Wp : 0.0) + (last ? (double)h->H * h->W : 0.0))));
+              CF_HIP(h, launch_convex_upsample(h->coords1, 0, h->maskbuf, 576, B, h8, w8, up, last ? flow_final : nullptr, h->H,
+                                               h->W, h->padH, h->padW, last ? flag : nullptr, nullptr, nullptr, su)); }
         }
         if (su != st) {
             CF_HIP(h, hipEventRecord(h->ev_up, su));
@@ -1245,9 +1354,10 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
     if (up_pending) CF_HIP(h, hipStreamWaitEvent(st, h->ev_up, 0));
     if (flow_low) {
         // flow_init of the returned dict = coords1 - coords0 at 1/8 resolution (DCEIFlow.py:297)
-        CF_HIP(h, launch_upflow(h->coords1, B, h8, w8, 1, flow_low, nullptr, 0, 0, 0, 0, nullptr, st));
+        { PROF(h, st, "flow_low", 16.0 * B * N); CF_HIP(h, launch_upflow(h->coords1, B, h8, w8, 1, flow_low, nullptr, 0, 0, 0, 0, nullptr, st)); }
     }
     h->fmap2_valid = eraft;
+    jg.disarm();
     return CF_OK;
 }
 
@@ -1262,7 +1372,7 @@ static int idnet_forward(cf_handle* h, const float* ev, const float* flow_init, 
     const long N = h->N;
     const int BT = B * T;
     // deblur every bin along the initial flow (zero flow is not an identity: align_corners quirk)
-    CF_HIP(h, launch_idn_deblur(ev, flow_init, h->idDeblur, B, T, h->H, h->W, h->padH, h->padW, st));
+    { PROF(h, st, "idn.deblur", 4.0 * B * (T * ((double)h->H * h->W + (double)Hp * Wp) + (flow_init ? 2.0 * Hp * Wp : 0.0))); CF_HIP(h, launch_idn_deblur(ev, flow_init, h->idDeblur, B, T, h->H, h->W, h->padH, h->padW, st)); }
     // LiteEncoder on all B*T bins at once (they are independent of the GRU state)
     auto K = [&](const std::string& k) -> const PackedConv& { return h->conv["idn." + k]; };
     int Hc = h->H1, Wc = h->W1;
@@ -1330,11 +1440,13 @@ static int idnet_forward(cf_handle* h, const float* ev, const float* flow_init, 
         CF_HIP(h, run_conv(h, m2, B, st));
         if (hd == 0) {
             float* delta = hist ? hist + (long)B * 2 * Hp * Wp : h->idDelta;
-            CF_HIP(h, launch_convex_upsample(h->idDflow, 1, h->maskbuf, 576, B, h8, w8, delta, flow_final, h->H, h->W, h->padH,
-                                             h->padW, flag, flow_init, hist, st));
+            { PROF(h, st, "convex_upsample", 4.0 * B * (578.0 * N + 2.0 * ((double)Hp * Wp * (2 + (flow_init ? 1 : 0) + (hist ? 1 : 0)) + (double)h->H * h->W)));
+              CF_HIP(h, launch_convex_upsample(h->idDflow, 1, h->maskbuf, 576, B, h8, w8, delta, flow_final, h->H, h->W, h->padH,
+                                               h->padW, flag, flow_init, hist, st)); }
         } else {
-            CF_HIP(h, launch_convex_upsample(h->idDflow, 1, h->maskbuf, 576, B, h8, w8, next_flow, nullptr, h->H, h->W, h->padH,
-                                             h->padW, nullptr, nullptr, nullptr, st));
+            { PROF(h, st, "convex_upsample", 4.0 * B * (578.0 * N + 2.0 * Hp * Wp));
+              CF_HIP(h, launch_convex_upsample(h->idDflow, 1, h->maskbuf, 576, B, h8, w8, next_flow, nullptr, h->H, h->W, h->padH,
+                                               h->padW, nullptr, nullptr, nullptr, st)); }
         }
     }
     return CF_OK;
@@ -1347,7 +1459,8 @@ extern "C" int cf_flow_forward(cf_handle* h, const float* in0, const float* in1,
     if (!h->finalized || !h->has_flow) return h->fail(CF_ERR_STATE, "cf_flow_forward: flow-net weights not finalised");
     if (h->cfg.mode == CF_MODE_CISTA) return h->fail(CF_ERR_UNSUPPORTED, "cf_flow_forward: handle has no flow network");
     if (!in0 || !flow_final) return h->fail(CF_ERR_ARG, "cf_flow_forward: null pointer");
-    CF_HIP(h, hipSetDevice(h->cfg.device));
+    DeviceGuard dg(h->cfg.device);
+    if (!dg.ok) return h->fail(CF_ERR_HIP, "hipSetDevice failed");
     if (h->cfg.mode == CF_MODE_IDNET)   // flow_low = next_flow (padded), flow_preds = {flow_total, delta_flow}
         return idnet_forward(h, in0, flow_init, flow_final, flow_low, flow_preds, h->flag, static_cast<hipStream_t>(stream));
     if (!in1) return h->fail(CF_ERR_ARG, "cf_flow_forward: null pointer");
@@ -1379,7 +1492,8 @@ extern "C" int cf_step(cf_handle* h, const float* in0, const float* in1, const f
         return h->fail(CF_ERR_ARG, "cf_step: null pointer");
     if ((h_prev == nullptr) != (cc_prev == nullptr)) return h->fail(CF_ERR_ARG, "cf_step: h_prev/cc_prev must come together");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    CF_HIP(h, hipSetDevice(h->cfg.device));
+    DeviceGuard dg(h->cfg.device);
+    if (!dg.ok) return h->fail(CF_ERR_HIP, "hipSetDevice failed");
     int rc;
     h->phase_collect();
     h->phase_mark(0, st);
@@ -1393,17 +1507,17 @@ extern "C" int cf_step(cf_handle* h, const float* in0, const float* in1, const f
     const float* flow = flow_final;
     if (gt_flow) {   // e2v_model.py:181-182
         flow = gt_flow;
-        CF_HIP(h, launch_any_nonzero(gt_flow, (long)h->B * 2 * h->H * h->W, h->flag, st));
+        { PROF(h, st, "any_nonzero", 8.0 * h->B * h->H * h->W); CF_HIP(h, launch_any_nonzero(gt_flow, (long)h->B * 2 * h->H * h->W, h->flag, st)); }
     }
     const int bwd = h->cfg.warp_mode == CF_WARP_BACKWARD ? 1 : 0;
     const long HW = (long)h->H * h->W, hw = (long)h->h * h->w;
     const int c2 = 2 * h->bc;
     // `if not flow_final.any()` -> device flag; flag == 0 makes the warps pass-through copies (:184-191)
-    CF_HIP(h, launch_warp(rec_img0, 1, HW, flow, h->H, h->W, h->warpedI, 1, HW, h->B, 1, h->H, h->W, bwd, h->flag, st));
+    { PROF(h, st, "warp.I", 16.0 * h->B * HW); CF_HIP(h, launch_warp(rec_img0, 1, HW, flow, h->H, h->W, h->warpedI, 1, HW, h->B, 1, h->H, h->W, bwd, h->flag, st)); }
     const float* zin = nullptr;
     if (z_prev) {
         float* zw = z_warped_out ? z_warped_out : h->zwarp;
-        CF_HIP(h, launch_warp(z_prev, c2, hw * c2, flow, h->H, h->W, zw, c2, hw * c2, h->B, c2, h->h, h->w, bwd, h->flag, st));
+        { PROF(h, st, "warp.Z", 4.0 * h->B * hw * (2 * c2 + 2)); CF_HIP(h, launch_warp(z_prev, c2, hw * c2, flow, h->H, h->W, zw, c2, hw * c2, h->B, c2, h->h, h->w, bwd, h->flag, st)); }
         zin = zw;
     }
     // CISTA consumes the current voxel grid: in0 for eiflow, in1 (= image2) for eraft (e2v_model.py:194,246)
@@ -1569,6 +1683,25 @@ extern "C" int cf_op_corr_lookup(const float* fmap1, const float* fmap2, const f
 extern "C" int cf_quantize_u8(const float* img, unsigned char* out, long long n, void* stream) {
     if (!img || !out || n <= 0) return CF_ERR_ARG;
     return launch_quantize_u8(img, out, (long)n, static_cast<hipStream_t>(stream)) == hipSuccess ? CF_OK : CF_ERR_HIP;
+}
+
+// f-3: evaluation metrics on the device (metrics.hip); stateless, asynchronous, results stay on the device
+extern "C" size_t cf_metrics_scratch_doubles(void) { return (size_t)metrics_scratch_doubles(); }
+extern "C" int cf_metrics_recon(const float* rec, const float* target, long long n, double* out2, double* scratch, void* stream) {
+    if (!rec || !target || !out2 || !scratch || n <= 0) return CF_ERR_ARG;
+    return launch_metrics_recon(rec, target, (long)n, out2, scratch, static_cast<hipStream_t>(stream)) == hipSuccess ? CF_OK : CF_ERR_HIP;
+}
+extern "C" int cf_metrics_flow(const float* flow, const float* gt_flow, const float* gt_img0, const float* gt_img1,
+                               const float* flow_valid, int B, int H, int W, int warp_mode, float max_flow, double* out6,
+                               double* scratch, void* stream) {
+    if (!flow || !gt_flow || !gt_img0 || !gt_img1 || !out6 || !scratch || B < 1 || H < 2 || W < 2) return CF_ERR_ARG;
+    return launch_metrics_flow(flow, gt_flow, gt_img0, gt_img1, flow_valid, B, H, W, warp_mode == CF_WARP_BACKWARD ? 1 : 0, max_flow,
+                               out6, scratch, static_cast<hipStream_t>(stream)) == hipSuccess ? CF_OK : CF_ERR_HIP;
+}
+extern "C" int cf_metrics_fwl(const float* voxel, const float* flow, int B, int C, int H, int W, double* out3, double* scratch,
+                              void* stream) {
+    if (!voxel || !flow || !out3 || !scratch || B < 1 || C < 2 || H < 2 || W < 2) return CF_ERR_ARG;
+    return launch_metrics_fwl(voxel, flow, B, C, H, W, out3, scratch, static_cast<hipStream_t>(stream)) == hipSuccess ? CF_OK : CF_ERR_HIP;
 }
 
 extern "C" int cf_events_to_voxel(const double* events, const int64_t* offsets, int B, int bins, int H, int W, float* voxel,

@@ -11,6 +11,16 @@
 
 namespace cf {
 
+// What the last launcher on this thread put on its stream (kernel symbol, total work-items = rocprofv3's
+// Grid_Size): the per-launch profiler of cf_api.hip reads it so that its HIP-event table can be joined with a
+// rocprofv3 --kernel-trace of the same run by (kernel, grid).
+struct LaunchInfo { const char* kernel; long threads; };
+extern thread_local LaunchInfo g_last_launch;
+inline void note_launch(const char* kernel, dim3 g, dim3 b) {
+    g_last_launch.kernel = kernel;
+    g_last_launch.threads = (long)g.x * g.y * g.z * b.x * b.y * b.z;
+}
+
 // ---------------------------------------------------------------------------
 // Implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
 //   M = output pixels of one image, N = output channels, K = taps * Cin.
@@ -197,5 +207,17 @@ hipError_t launch_upsample2x_nhwc(const float* src, int s_ld, long s_bs, float* 
 
 // f-2: np.uint8(pred * 255.) of the reconstructed frames (test_with_flow.py:174)
 hipError_t launch_quantize_u8(const float* x, unsigned char* out, long n, hipStream_t s);
+
+// f-3: evaluation metrics on the device (metrics.hip).  out / scratch are device doubles; scratch holds
+// metrics_scratch_doubles() entries.  All asynchronous on `s`, deterministic (fixed-order fp64 folds).
+long metrics_scratch_doubles();
+// out[2] = {mse, psnr}   (loss.py:15-24, nn.MSELoss)
+hipError_t launch_metrics_recon(const float* rec, const float* tgt, long n, double* out, double* scratch, hipStream_t s);
+// out[6] = {photo_loss, epe, 1px, 3px, 5px, out}   (FlowL1LossDict.evaluate, loss.py:237-265); valid nullable
+hipError_t launch_metrics_flow(const float* flow, const float* gt, const float* img0, const float* img1, const float* valid,
+                               int B, int H, int W, int backward, float max_flow, double* out, double* scratch, hipStream_t s);
+// out[3] = {var(warped events | flow), var(warped events | zero flow), ratio = FWL}   (loss.py:27-83, test_wo_flow.py:161)
+hipError_t launch_metrics_fwl(const float* voxel, const float* flow, int B, int C, int H, int W, double* out, double* scratch,
+                              hipStream_t s);
 
 }  // namespace cf

@@ -24,6 +24,8 @@
 
 namespace cf {
 
+thread_local LaunchInfo g_last_launch = {"", 0};
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -958,6 +960,7 @@ template <int BM, int BN, int WM, int WN, int WK, int PREC, int KCW = 16>
 static hipError_t launch_tp(const ConvParams& p, int batch, hipStream_t s) {
     const int M = p.Ho * p.Wo;
     dim3 grid(((M + BM - 1) / BM) * ((p.cout + BN - 1) / BN) * batch);
+    g_last_launch.threads = (long)grid.x * 256;
     if (p.a_mode == A_NHWC) {
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, WK, A_NHWC, PREC, KCW>), grid, dim3(256), 0, s, p);
     } else if constexpr (WK == 1 && KCW == 16) {
@@ -1403,6 +1406,7 @@ static hipError_t launch_dma(const ConvParams& p, int batch, hipStream_t s) {
     if (p.a_mode != A_NHWC || p.prec != 0 || !stage_ok(p, KCW * WK)) return hipErrorInvalidValue;
     const int M = p.Ho * p.Wo;
     dim3 grid(((M + BM - 1) / BM) * ((p.cout + BN - 1) / BN) * batch);
+    g_last_launch.threads = (long)grid.x * 256;
     hipLaunchKernelGGL((conv_dma_kernel<BM, BN, WM, WN, WK, KCW, NBUF>), grid, dim3(256), 0, s, p);
     return hipGetLastError();
 }
@@ -1594,6 +1598,7 @@ static hipError_t launch_smalln(const ConvParams& p, int batch, hipStream_t s, b
         int RY = 12;
         while (RY > 3 && (long)((p.Win + ppw - 1) / ppw) * ((p.Hin + RY - 1) / RY) * batch < 1024) RY -= 3;
         dim3 grid((p.Win + ppw - 1) / ppw, (p.Hin + RY - 1) / RY, batch);
+        note_launch(p.cout == 1 ? "conv_small3x3_kernel<1>" : "conv_small3x3_kernel<2>", grid, dim3(256));
         if (p.cout == 1) hipLaunchKernelGGL(conv_small3x3_kernel<1>, grid, dim3(256), 0, s, p, lpp, RY);
         else hipLaunchKernelGGL(conv_small3x3_kernel<2>, grid, dim3(256), 0, s, p, lpp, RY);
         return hipGetLastError();
@@ -1601,6 +1606,7 @@ static hipError_t launch_smalln(const ConvParams& p, int batch, hipStream_t s, b
     const int ppw = 256 / lpp;
     const int M = p.Ho * p.Wo;
     dim3 grid((M + ppw - 1) / ppw, batch);
+    note_launch(p.cout == 1 ? "conv_smalln_kernel<1>" : "conv_smalln_kernel<2>", grid, dim3(256));
     if (p.cout == 1) hipLaunchKernelGGL(conv_smalln_kernel<1>, grid, dim3(256), 0, s, p, lpp);
     else hipLaunchKernelGGL(conv_smalln_kernel<2>, grid, dim3(256), 0, s, p, lpp);
     return hipGetLastError();
@@ -1773,6 +1779,7 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
         }
     }
     if (tile_used) *tile_used = tile;
+    g_last_launch.kernel = conv_tile_name(tile);
     if (p.prec != 0 && p.prec != 1 && p.prec != 3) return hipErrorInvalidValue;
     if (p.prec != 0) {          // f16 modes: pre-split weights when there are some, else split B while staging
         if (p.w16 && p.w_bs == 0) {

@@ -131,6 +131,7 @@ hipError_t launch_warp(const float* img, int img_ld, long img_bs, const float* f
                         : 0;
     const long total = (long)B * H * W * cq;
     const long blocks = (total + 255) / 256;
+    note_launch("warp_kernel", dim3((unsigned)blocks), dim3(256));
     hipLaunchKernelGGL(warp_kernel, dim3((unsigned)blocks), dim3(256), 0, s, img, img_ld, img_bs, flow, Hf, Wf, out,
                        out_ld, out_bs, B, C, H, W, backward, flag, cq, vec);
     return hipGetLastError();
@@ -153,6 +154,7 @@ hipError_t launch_any_nonzero(const float* x, long n, int* flag, hipStream_t s) 
     if (e != hipSuccess) return e;
     long blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
+    note_launch("any_nonzero_kernel", dim3((unsigned)blocks), dim3(256));
     hipLaunchKernelGGL(any_nonzero_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, n, flag);
     return hipGetLastError();
 }
@@ -267,6 +269,7 @@ __global__ __launch_bounds__(256) void inorm_final_kernel(const double* __restri
 hipError_t launch_inorm_final(const double* partial, int nchunk, int B, int HW, int C, float eps, float* stats,
                               hipStream_t s) {
     if (!partial || !stats || nchunk <= 0 || B <= 0 || HW <= 0 || C <= 0) return hipErrorInvalidValue;
+    note_launch("inorm_final_kernel", dim3((C + 3) / 4, B), dim3(256));
     hipLaunchKernelGGL(inorm_final_kernel, dim3((C + 3) / 4, B), dim3(256), 0, s, partial, nchunk, C, HW, eps, stats);
     return hipGetLastError();
 }
@@ -277,6 +280,7 @@ hipError_t launch_inorm_stats(const float* x, int ld, long bs, int B, int HW, in
         (reinterpret_cast<uintptr_t>(x) & 15) != 0)
         return hipErrorInvalidValue;
     const int nchunk = (HW + IN_CHUNK - 1) / IN_CHUNK;
+    note_launch("inorm_partial_kernel", dim3(nchunk, B), dim3(256));
     hipLaunchKernelGGL(inorm_partial_kernel, dim3(nchunk, B), dim3(256), 0, s, x, ld, bs, HW, C, partial, nchunk);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -326,6 +330,7 @@ hipError_t launch_inorm_apply(const float* x, int ld, long bs, const float* stat
     if (res && ((res_ld % 4) != 0 || (res_bs % 4) != 0)) return hipErrorInvalidValue;
     const long per_image = (long)HW * (C / 4);
     if (per_image >= 0x7FFFFFFFL || B > 65535) return hipErrorInvalidValue;
+    note_launch("inorm_apply_kernel", dim3((unsigned)((per_image + 255) / 256), B), dim3(256));
     hipLaunchKernelGGL(inorm_apply_kernel, dim3((unsigned)((per_image + 255) / 256), B), dim3(256), 0, s, x, ld, bs, stats, res,
                        res_ld, res_bs, res_stats, out, out_ld, out_bs, B, HW, C);
     return hipGetLastError();
@@ -352,6 +357,7 @@ __global__ void corr_pool_kernel(const float* __restrict__ src, float* __restric
 hipError_t launch_corr_pool(const float* src, float* dst, long rows, int Hs, int Ws, hipStream_t s) {
     if (!src || !dst || rows <= 0 || Hs < 2 || Ws < 2) return hipErrorInvalidValue;
     const long total = rows * (Hs / 2) * (Ws / 2);
+    note_launch("corr_pool_kernel", dim3((unsigned)((total + 255) / 256)), dim3(256));
     hipLaunchKernelGGL(corr_pool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, dst, rows, Hs, Ws);
     return hipGetLastError();
 }
@@ -424,6 +430,7 @@ hipError_t launch_corr_lookup(const LookupParams& p, hipStream_t s) {
     for (int l = 0; l < p.nlevels; ++l)
         if (!p.lvl[l] || p.lh[l] < 2 || p.lw[l] < 2) return hipErrorInvalidValue;
     const long nq = (long)p.B * p.h8 * p.w8;
+    note_launch("corr_lookup_kernel", dim3((unsigned)((nq + 3) / 4)), dim3(256));
     hipLaunchKernelGGL(corr_lookup_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, p);
     return hipGetLastError();
 }
@@ -446,6 +453,7 @@ __global__ void coords_init_kernel(float* coords1, const float* flow_init, int B
 hipError_t launch_coords_init(float* coords1, const float* flow_init, int B, int h8, int w8, hipStream_t s) {
     if (!coords1 || B <= 0 || h8 <= 0 || w8 <= 0) return hipErrorInvalidValue;
     const long total = (long)B * 2 * h8 * w8;
+    note_launch("coords_init_kernel", dim3((unsigned)((total + 255) / 256)), dim3(256));
     hipLaunchKernelGGL(coords_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, coords1, flow_init, B,
                        h8, w8);
     return hipGetLastError();
@@ -495,6 +503,7 @@ hipError_t launch_upflow(const float* coords1, int B, int h8, int w8, int ds, fl
     if (!coords1 || B <= 0 || h8 <= 0 || w8 <= 0 || ds <= 0) return hipErrorInvalidValue;
     if (flow_final && (H + padH != h8 * ds || W + padW != w8 * ds)) return hipErrorInvalidValue;
     const long total = (long)B * 2 * h8 * ds * w8 * ds;
+    note_launch("upflow_kernel", dim3((unsigned)((total + 255) / 256)), dim3(256));
     hipLaunchKernelGGL(upflow_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, coords1, B, h8, w8, ds,
                        flow_up, flow_final, H, W, padH, padW, flag);
     return hipGetLastError();
@@ -584,6 +593,7 @@ hipError_t launch_convex_upsample(const float* coords1, int coords_is_flow, cons
     if (!coords1 || !mask || mask_ld < 576 || B <= 0 || h8 <= 0 || w8 <= 0) return hipErrorInvalidValue;
     if (flow_final && (H + padH != h8 * 8 || W + padW != w8 * 8)) return hipErrorInvalidValue;
     const long nq = (long)B * h8 * w8;
+    note_launch("convex_upsample_kernel", dim3((unsigned)((nq + 3) / 4)), dim3(256));
     hipLaunchKernelGGL(convex_upsample_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, coords1, coords_is_flow,
                        mask, mask_ld, B, h8, w8, flow_up, flow_final, H, W, padH, padW, flag, add, total_out);
     return hipGetLastError();
@@ -633,6 +643,7 @@ hipError_t launch_idn_deblur(const float* bins, const float* flow, float* out, i
                              int padW, hipStream_t s) {
     if (!bins || !out || B <= 0 || T < 2 || H <= 1 || W <= 1) return hipErrorInvalidValue;
     const long total = (long)B * T * (H + padH) * (W + padW);
+    note_launch("idn_deblur_kernel", dim3((unsigned)((total + 255) / 256)), dim3(256));
     hipLaunchKernelGGL(idn_deblur_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, bins, flow, out, B, T, H, W,
                        padH, padW);
     return hipGetLastError();
@@ -709,11 +720,14 @@ hipError_t launch_events_to_voxel(const double* events, const long* offsets, int
     const long per_seq = (long)bins * H * W;
     hipError_t e = hipMemsetAsync(voxel, 0, sizeof(float) * per_seq * B, s);
     if (e != hipSuccess) return e;
+    note_launch("events_scatter_kernel", dim3(64, B), dim3(256));
     hipLaunchKernelGGL(events_scatter_kernel, dim3(64, B), dim3(256), 0, s, events, offsets, B, bins, H, W, voxel);
     if (normalize) {
         e = hipMemsetAsync(stats, 0, sizeof(double) * 3 * B, s);
         if (e != hipSuccess) return e;
+        note_launch("voxel_stats_kernel", dim3(64, B), dim3(256));
         hipLaunchKernelGGL(voxel_stats_kernel, dim3(64, B), dim3(256), 0, s, voxel, per_seq, stats);
+        note_launch("voxel_normalize_kernel", dim3(64, B), dim3(256));
         hipLaunchKernelGGL(voxel_normalize_kernel, dim3(64, B), dim3(256), 0, s, voxel, per_seq, stats);
     }
     return hipGetLastError();
@@ -758,12 +772,14 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, int src_ld, f
 
 hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int dst_ld, int B, int C, int HW, hipStream_t s) {
     if (!src || !dst || dst_ld < C) return hipErrorInvalidValue;
+    note_launch("nchw_to_nhwc_kernel", dim3((HW + 31) / 32, (C + 31) / 32, B), dim3(256));
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((HW + 31) / 32, (C + 31) / 32, B), dim3(256), 0, s, src, dst, dst_ld, B, C,
                        HW);
     return hipGetLastError();
 }
 hipError_t launch_nhwc_to_nchw(const float* src, int src_ld, float* dst, int B, int C, int HW, hipStream_t s) {
     if (!src || !dst || src_ld < C) return hipErrorInvalidValue;
+    note_launch("nhwc_to_nchw_kernel", dim3((HW + 31) / 32, (C + 31) / 32, B), dim3(256));
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((HW + 31) / 32, (C + 31) / 32, B), dim3(256), 0, s, src, src_ld, dst, B, C,
                        HW);
     return hipGetLastError();
@@ -812,6 +828,7 @@ hipError_t launch_upsample2x_nhwc(const float* src, int s_ld, long s_bs, float* 
         return hipErrorInvalidValue;
     if (2 * Hs > 65535 || B > 65535) return hipErrorInvalidValue;
     const int row = 2 * Ws * (C / 4);
+    note_launch("upsample2x_nhwc_kernel", dim3((unsigned)((row + 255) / 256), 2 * Hs, B), dim3(256));
     hipLaunchKernelGGL(upsample2x_nhwc_kernel, dim3((unsigned)((row + 255) / 256), 2 * Hs, B), dim3(256), 0, s, src, s_ld, s_bs, dst, d_ld,
                        d_bs, B, Hs, Ws, C);
     return hipGetLastError();
@@ -838,6 +855,7 @@ __global__ __launch_bounds__(256) void quantize_u8_kernel(const float* __restric
 hipError_t launch_quantize_u8(const float* x, unsigned char* out, long n, hipStream_t s) {
     if (!x || !out || n <= 0) return hipErrorInvalidValue;
     const long threads = (n + 3) / 4;
+    note_launch("quantize_u8_kernel", dim3((unsigned)((threads + 255) / 256)), dim3(256));
     hipLaunchKernelGGL(quantize_u8_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, x, out, n);
     return hipGetLastError();
 }

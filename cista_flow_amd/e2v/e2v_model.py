@@ -88,7 +88,7 @@ class CistaLSTCNet(nn.Module):
         p = _lib.ptr
         h.check(h.lib.cf_cista_forward(h.h, p(events.contiguous()), p(prev_image.contiguous()), p(c_prev), p(z_prev),
                                        p(h_prev), p(cc_prev), p(I), p(c), p(z), p(hh), p(cc),
-                                       _lib.current_stream_ptr()), "cf_cista_forward")
+                                       _lib.current_stream_ptr(dev)), "cf_cista_forward")
         return I, [c, z, (hh, cc)]
 
 
@@ -148,7 +148,7 @@ class _HipFlowRec(BaseFlowRec):
         p = _lib.ptr
         h.check(h.lib.cf_step(h.h, p(in0.contiguous()), p(in1.contiguous()), p(rec0.contiguous()), p(flow_init),
                               p(gt_flow), p(c_prev), p(z_prev), p(h_prev), p(cc_prev), p(I), p(flow_final), p(flow_low),
-                              p(preds), p(z_warp), p(c), p(z), p(hh), p(cc), _lib.current_stream_ptr()), "cf_step")
+                              p(preds), p(z_warp), p(c), p(z), p(hh), p(cc), _lib.current_stream_ptr(dev)), "cf_step")
         if z_warp is not None:
             states[1] = z_warp      # e2v_model.py:191 (pass-through copy when flow_final is all zero)
         batch_flow = dict(flow_preds=[preds[i] for i in range(iters)] if preds is not None else [],
@@ -193,7 +193,11 @@ class ERAFTCistaNet(_HipFlowRec):
         self.event_flownet = ERAFT(args)
         self.flow_iters = 12         # ERAFT.forward default iters (eraft.py:114)
         self._backend = None
-        self.reuse_prev_features = True   # see forward()
+        # Opt-in: reuse fnet(event_voxel_old) from the previous call when event_voxel_old IS the tensor that
+        # was event_voxel then.  The check is object identity + tensor._version, which cannot see writes that bypass
+        # autograd's version counter (numpy / DLPack / __cuda_array_interface__ views, other libraries' kernels,
+        # .data-level copies): enable only when the driver never writes into a voxel grid after handing it over.
+        self.reuse_prev_features = False
         self._last_ev = None
 
     def forward(self, batch_data, states, batch_gt=dict([])):
@@ -266,7 +270,7 @@ class IDCistaNet(_HipFlowRec):
         evc = ev.contiguous()
         h.check(h.lib.cf_step(h.h, p(evc), p(evc), p(rec0.contiguous()), p(flow_init), p(gt_flow), p(c_prev), p(z_prev),
                               p(h_prev), p(cc_prev), p(I), p(flow_final), p(next_flow), p(hist), p(z_warp), p(c), p(z),
-                              p(hh), p(cc), _lib.current_stream_ptr()), "cf_step")
+                              p(hh), p(cc), _lib.current_stream_ptr(dev)), "cf_step")
         if z_warp is not None:
             states[1] = z_warp
         d0 = flow_init if flow_init is not None else torch.zeros_like(hist[1])

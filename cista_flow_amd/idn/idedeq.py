@@ -61,7 +61,7 @@ class IDEDEQIDO(nn.Module):
         next_flow = torch.empty((B, 2, Hp, Wp), dtype=torch.float32, device=dev)
         hist = torch.empty((2, B, 2, Hp, Wp), dtype=torch.float32, device=dev)
         h.check(h.lib.cf_flow_forward(h.h, _lib.ptr(event_bins.contiguous()), None, _lib.ptr(flow_init), _lib.ptr(flow_final),
-                                      _lib.ptr(next_flow), _lib.ptr(hist), _lib.current_stream_ptr()), "cf_flow_forward")
+                                      _lib.ptr(next_flow), _lib.ptr(hist), _lib.current_stream_ptr(dev)), "cf_flow_forward")
         d0 = flow_init if flow_init is not None else torch.zeros_like(hist[1])
         return {'flow_final': flow_final, 'next_flow': next_flow, 'delta_flow': torch.stack([d0, hist[1]], 1),
                 'flow_preds': [hist[0]]}

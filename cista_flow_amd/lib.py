@@ -20,6 +20,7 @@ SYMBOLS = [
     "cf_finalize_weights", "cf_warp", "cf_cista_forward", "cf_flow_forward", "cf_step",
     "cf_op_conv2d", "cf_op_instance_norm_relu", "cf_op_corr_lookup", "cf_op_nchw_to_nhwc",
     "cf_op_nhwc_to_nchw", "cf_profile_enable", "cf_profile_read", "cf_conv_tile_name", "cf_profile_report", "cf_op_conv2d_bench", "cf_events_to_voxel", "cf_op_conv2d_inorm_stats", "cf_quantize_u8", "cf_hint_prev_grid",
+    "cf_profile_report_json", "cf_metrics_scratch_doubles", "cf_metrics_recon", "cf_metrics_flow", "cf_metrics_fwl",
 ]
 
 
@@ -87,6 +88,14 @@ def load():
     lib.cf_events_to_voxel.restype = i
     lib.cf_quantize_u8.argtypes = [fp, fp, C.c_longlong, vp]
     lib.cf_quantize_u8.restype = i
+    lib.cf_metrics_scratch_doubles.argtypes = []
+    lib.cf_metrics_scratch_doubles.restype = C.c_size_t
+    lib.cf_metrics_recon.argtypes = [fp, fp, C.c_longlong, fp, fp, vp]
+    lib.cf_metrics_recon.restype = i
+    lib.cf_metrics_flow.argtypes = [fp, fp, fp, fp, fp, i, i, i, i, C.c_float, fp, fp, vp]
+    lib.cf_metrics_flow.restype = i
+    lib.cf_metrics_fwl.argtypes = [fp, fp, i, i, i, i, fp, fp, vp]
+    lib.cf_metrics_fwl.restype = i
     lib.cf_hint_prev_grid.argtypes = [vp, i]
     lib.cf_hint_prev_grid.restype = i
     lib.cf_profile_enable.argtypes = [vp, i]
@@ -95,6 +104,8 @@ def load():
     lib.cf_profile_read.restype = i
     lib.cf_profile_report.argtypes = [vp]
     lib.cf_profile_report.restype = C.c_char_p
+    lib.cf_profile_report_json.argtypes = [vp]
+    lib.cf_profile_report_json.restype = C.c_char_p
     lib.cf_conv_tile_name.argtypes = [i]
     lib.cf_conv_tile_name.restype = C.c_char_p
     _lib = lib
@@ -108,9 +119,11 @@ def ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
-def current_stream_ptr():
+def current_stream_ptr(device=None):
+    """torch's current stream ON `device` (a tensor's device, not the process's current device: with the model on
+    cuda:1 and current device cuda:0 the two differ as soon as a non-default stream is in use)."""
     import torch
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 def check_f32_cuda(t, name, shape=None):
@@ -156,7 +169,7 @@ class Handle:
             keep.append(t)
             shp = (C.c_int64 * max(1, t.dim()))(*t.shape)
             self.check(self.lib.cf_load_weights(self.h, k.encode(), ptr(t), shp, t.dim()), "cf_load_weights(%s)" % k)
-        self.check(self.lib.cf_finalize_weights(self.h, current_stream_ptr()), "cf_finalize_weights")
+        self.check(self.lib.cf_finalize_weights(self.h, current_stream_ptr(self.cfg.device)), "cf_finalize_weights")
         del keep
 
     def profile_enable(self, on=True):
@@ -175,6 +188,11 @@ class Handle:
 
     def profile_report(self):
         return self.lib.cf_profile_report(self.h).decode()
+
+    def profile_rows(self):
+        """Rows of the last profile_read over both roofline classes: tag, kernel, grid, class, launches, ms, work."""
+        import json
+        return json.loads(self.lib.cf_profile_report_json(self.h).decode())
 
     @property
     def workspace_bytes(self):

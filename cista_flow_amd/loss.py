@@ -1,0 +1,132 @@
+"""Evaluation metrics of the reference's drivers on the GPU (reference: loss.py).
+
+Same class / function names and return conventions as the reference (`ReconLoss.evaluate` and
+`FlowL1LossDict.evaluate` return dicts of Python floats, `voxel_warping_flow_loss` a 0-dim tensor), so
+`from loss import ReconLoss, voxel_warping_flow_loss` (test_wo_flow.py:20) can point here.  The arithmetic runs in
+csrc/metrics.hip; only a few doubles per frame cross PCIe.
+
+Not built: SSIM and LPIPS (`pytorch_msssim`, `lpips` + torchvision weights are third-party packages that are absent
+offline) -- `ReconLoss.evaluate` returns `mse` and `psnr` only -- and the training losses (`forward` methods).
+"""
+import torch
+import torch.nn as nn
+
+from . import lib as _lib
+
+
+def _scratch(dev):
+    L = _lib.load()
+    return torch.empty(int(L.cf_metrics_scratch_doubles()), dtype=torch.float64, device=dev)
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed (%d)" % (what, rc))
+
+
+def recon_metrics(rec_img, target_img):
+    """-> float64 CUDA tensor [2] = (mse, psnr); asynchronous (no host sync)."""
+    _lib.check_f32_cuda(rec_img, "rec_img")
+    _lib.check_f32_cuda(target_img, "target_img", tuple(rec_img.shape))
+    a, b = rec_img.contiguous(), target_img.contiguous()
+    dev = a.device
+    out = torch.empty(2, dtype=torch.float64, device=dev)
+    L = _lib.load()
+    with torch.cuda.device(dev):
+        _check(L.cf_metrics_recon(_lib.ptr(a), _lib.ptr(b), a.numel(), _lib.ptr(out), _lib.ptr(_scratch(dev)),
+                                  _lib.current_stream_ptr(dev)), "cf_metrics_recon")
+    return out
+
+
+class PSNR(nn.Module):
+    """loss.py:15-24 (data_range 1 only, as ReconLoss builds it)."""
+
+    def __init__(self, data_range=1):
+        super().__init__()
+        if data_range != 1:
+            raise NotImplementedError("PSNR: only data_range=1 is used by CISTA-Flow")
+        self.data_range = data_range
+
+    def forward(self, imgs1, imgs2):
+        return recon_metrics(imgs1, imgs2)[1].float()
+
+
+class ReconLoss(nn.Module):
+    """ReconLoss.evaluate (loss.py:316-328) without its third-party half (ssim, lpips)."""
+
+    def __init__(self, frame_warper=None, lpips_net='alex'):
+        super().__init__()
+        self.warp_fn = frame_warper
+        self.psnr_fn = PSNR(data_range=1)
+
+    def evaluate(self, rec_img, target_img):
+        m = recon_metrics(rec_img, target_img).cpu()
+        return {'mse': float(m[0]), 'psnr': float(m[1])}
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("training loss (loss.py:331-360) is out of scope of the inference hot path")
+
+
+def flow_metrics(flow_final, gt_flow, gt_img0, gt_img1, flow_valid=None, warp_mode='forward', max_flow=400.0):
+    """-> float64 CUDA tensor [6] = (photo_loss, epe, 1px, 3px, 5px, out); asynchronous."""
+    _lib.check_f32_cuda(flow_final, "flow_final")
+    B, two, H, W = flow_final.shape
+    if two != 2:
+        raise ValueError("flow_final must be [B,2,H,W]")
+    _lib.check_f32_cuda(gt_flow, "gt_flow", (B, 2, H, W))
+    _lib.check_f32_cuda(gt_img0, "gt_img0", (B, 1, H, W))
+    _lib.check_f32_cuda(gt_img1, "gt_img1", (B, 1, H, W))
+    if flow_valid is not None:
+        _lib.check_f32_cuda(flow_valid, "flow_valid", (B, 1, H, W))
+        flow_valid = flow_valid.contiguous()
+    dev = flow_final.device
+    out = torch.empty(6, dtype=torch.float64, device=dev)
+    L = _lib.load()
+    with torch.cuda.device(dev):
+        _check(L.cf_metrics_flow(_lib.ptr(flow_final.contiguous()), _lib.ptr(gt_flow.contiguous()), _lib.ptr(gt_img0.contiguous()),
+                                 _lib.ptr(gt_img1.contiguous()), _lib.ptr(flow_valid), B, H, W,
+                                 _lib.CF_WARP_FORWARD if warp_mode == 'forward' else _lib.CF_WARP_BACKWARD, float(max_flow),
+                                 _lib.ptr(out), _lib.ptr(_scratch(dev)), _lib.current_stream_ptr(dev)), "cf_metrics_flow")
+    return out
+
+
+class FlowL1LossDict(nn.Module):
+    """FlowL1LossDict.evaluate (loss.py:237-265)."""
+
+    def __init__(self, image_dim, frame_warper, ds=8, is_bi=False):
+        super().__init__()
+        self.gamma = 0.8
+        self.isbi = is_bi
+        self.max_flow = 400
+        self.warp_fn = frame_warper
+        self.image_dim = image_dim
+
+    def evaluate(self, flow_final, batch_target):
+        m = flow_metrics(flow_final, batch_target['gt_flow'], batch_target['gt_img0'], batch_target['gt_img1'],
+                         batch_target.get('flow_valid'), self.warp_fn.mode, self.max_flow).cpu()
+        keys = ['photo_loss', 'epe', '1px', '3px', '5px', 'out']
+        return {k: float(m[i]) for i, k in enumerate(keys)}
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("training loss (loss.py:267-312) is out of scope of the inference hot path")
+
+
+def fwl_metrics(voxel, flow):
+    """-> float64 CUDA tensor [3] = (var with flow, var with zero flow, FWL ratio of test_wo_flow.py:161)."""
+    _lib.check_f32_cuda(voxel, "voxel")
+    B, C, H, W = voxel.shape
+    _lib.check_f32_cuda(flow, "flow", (B, 2, H, W))
+    dev = voxel.device
+    out = torch.empty(3, dtype=torch.float64, device=dev)
+    L = _lib.load()
+    with torch.cuda.device(dev):
+        _check(L.cf_metrics_fwl(_lib.ptr(voxel.contiguous()), _lib.ptr(flow.contiguous()), B, C, H, W, _lib.ptr(out),
+                                _lib.ptr(_scratch(dev)), _lib.current_stream_ptr(dev)), "cf_metrics_fwl")
+    return out
+
+
+def voxel_warping_flow_loss(voxel, displacement, output_images=False, reverse_time=False):
+    """loss.py:27-83: variance of the event image obtained by warping voxel channel i along i/(C-1) of the flow."""
+    if output_images or reverse_time:
+        raise NotImplementedError("output_images / reverse_time are not used by the drivers (test_wo_flow.py:161)")
+    return fwl_metrics(voxel, displacement)[0].float()

@@ -27,8 +27,9 @@ def events_to_voxel_grid_batch(event_list, num_bins, width, height, normalize=Tr
     voxel = torch.empty((B, num_bins, height, width), dtype=torch.float32, device=dev)
     stats = torch.empty((B, 3), dtype=torch.float64, device=dev)
     L = _lib.load()
-    rc = L.cf_events_to_voxel(_lib.ptr(ev), _lib.ptr(offsets), B, num_bins, height, width, _lib.ptr(voxel), _lib.ptr(stats),
-                              1 if normalize else 0, _lib.current_stream_ptr())
+    with torch.cuda.device(dev):           # the stateless entry points launch on the CURRENT device
+        rc = L.cf_events_to_voxel(_lib.ptr(ev), _lib.ptr(offsets), B, num_bins, height, width, _lib.ptr(voxel), _lib.ptr(stats),
+                                  1 if normalize else 0, _lib.current_stream_ptr(dev))
     if rc != 0:
         raise RuntimeError("cf_events_to_voxel failed (%d)" % rc)
     return voxel

@@ -28,9 +28,12 @@ class FrameWarp(object):
         src = I.contiguous(memory_format=torch.channels_last) if Cc > 1 else I.contiguous()
         fl = flow.contiguous()
         out = torch.empty_like(src)
-        rc = L.cf_warp(None, _lib.ptr(src), _lib.ptr(fl), _lib.ptr(out), B, Cc, H, W, Hf, Wf,
-                       _lib.CF_WARP_FORWARD if self.mode == 'forward' else _lib.CF_WARP_BACKWARD,
-                       _lib.current_stream_ptr())
+        if fl.device != src.device:
+            raise RuntimeError("I and flow must live on the same GPU")
+        with torch.cuda.device(src.device):    # the stateless entry points launch on the CURRENT device
+            rc = L.cf_warp(None, _lib.ptr(src), _lib.ptr(fl), _lib.ptr(out), B, Cc, H, W, Hf, Wf,
+                           _lib.CF_WARP_FORWARD if self.mode == 'forward' else _lib.CF_WARP_BACKWARD,
+                           _lib.current_stream_ptr(src.device))
         if rc != 0:
             raise RuntimeError("cf_warp failed (%d)" % rc)
         return out

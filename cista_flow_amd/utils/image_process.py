@@ -38,7 +38,8 @@ def to_uint8(pred):
     _lib.check_f32_cuda(pred, "pred", tuple(pred.shape))
     x = pred.contiguous()
     out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
-    rc = L.cf_quantize_u8(_lib.ptr(x), out.data_ptr(), x.numel(), _lib.current_stream_ptr())
+    with torch.cuda.device(x.device):      # the stateless entry points launch on the CURRENT device
+        rc = L.cf_quantize_u8(_lib.ptr(x), out.data_ptr(), x.numel(), _lib.current_stream_ptr(x.device))
     if rc != 0:
         raise RuntimeError("cf_quantize_u8 failed (%d)" % rc)
     return out

@@ -46,7 +46,9 @@ typedef struct cf_config {
     int mode;           /* CF_MODE_* */
     int batch;          /* B: independent sequences held by this handle */
     int height, width;  /* image_dim (utils/configs.py:6); must be even */
-    int num_bins;       /* 5  (configs.py:18) */
+    int num_bins;       /* 5  (configs.py:18); the 7x7 encoder stems read the voxel grid through the planar gather
+                           convolution, whose K = 49*num_bins must be <= 256: num_bins <= 5 for eiflow / eraft
+                           (cf_finalize_weights fails with CF_ERR_UNSUPPORTED beyond that), <= 28 for CISTA alone */
     int base_channels;  /* 64 (configs.py:22) */
     int depth;          /* 5 ISTA iterations (configs.py:20) */
     int iters;          /* flow-net refinement iterations: 6 eiflow (DCEIFlow.py:143), 12 eraft */
@@ -120,16 +122,43 @@ int cf_events_to_voxel(const double* events, const int64_t* offsets, int B, int 
  * flow -> HSV colour coding (utils/data_io.py:9-29, defined by cv2.cartToPolar / cvtColor) stay on the host. */
 int cf_quantize_u8(const float* img, unsigned char* out, long long n, void* stream);
 
-/* measurement: when enabled, every convolution launch of the fused paths is bracketed by HIP events on
- * the launch stream and the library's side streams are folded into the caller's stream (kernels run one at
- * a time, so a duration is that kernel alone on the chip -- what a roofline fraction needs).  cf_profile_read synchronises them and returns, for conv tile kind t = 1..6
- * (index 0 = all), the summed launch duration in ms, the summed algorithmic flops (2*M*N*K with the
- * un-padded K) and the launch count, then clears the records.  cf_conv_tile_name(t) = kernel symbol. */
+/* f-3  evaluation metrics on the device (loss.py of the reference).  Stateless and asynchronous on
+ * `stream`; every result is written to DEVICE doubles (`out*`), so a caller reads a frame's scores with one small copy
+ * whenever it wants them.  scratch: cf_metrics_scratch_doubles() device doubles.  Deterministic (fixed-order fp64 folds).
+ *   cf_metrics_recon  out2 = {mse, psnr}: nn.MSELoss and PSNR(data_range=1) of ReconLoss.evaluate (loss.py:15-24,316-328;
+ *                     psnr = 100 when mse < 1e-10).  SSIM / LPIPS need pytorch_msssim / lpips (third-party, absent): not built.
+ *   cf_metrics_flow   out6 = {photo_loss, epe, 1px, 3px, 5px, out}: FlowL1LossDict.evaluate (loss.py:237-265).  flow,
+ *                     gt_flow NCHW [B][2][H][W]; gt_img0/1 [B][1][H][W]; flow_valid [B][1][H][W] or NULL (then
+ *                     exp(-50*(warp(gt_img0, gt_flow) - gt_img1)^2), loss.py:241); warp_mode = the FrameWarp mode;
+ *                     max_flow = 400 (loss.py:124).  epe / mag uses each pixel's own gt magnitude (the reference's
+ *                     expression only runs at batch 1, where this is the same thing).
+ *   cf_metrics_fwl    out3 = {var(sum_i warp_i(voxel_i; flow)), the same for zero flow, their ratio = FWL}
+ *                     (voxel_warping_flow_loss, loss.py:27-83; ratio as in test_wo_flow.py:161).  voxel [B][C][H][W]. */
+size_t cf_metrics_scratch_doubles(void);
+int cf_metrics_recon(const float* rec, const float* target, long long n, double* out2, double* scratch, void* stream);
+int cf_metrics_flow(const float* flow, const float* gt_flow, const float* gt_img0, const float* gt_img1,
+                    const float* flow_valid, int B, int H, int W, int warp_mode, float max_flow, double* out6,
+                    double* scratch, void* stream);
+int cf_metrics_fwl(const float* voxel, const float* flow, int B, int C, int H, int W, double* out3, double* scratch,
+                   void* stream);
+
+/* measurement: when enabled, EVERY kernel launch of the fused paths (convolutions and the HBM-class kernels: warp,
+ * up-sampling, InstanceNorm apply, correlation lookup / pyramid, flow up-sampling ...) is bracketed by HIP events on
+ * the launch stream and the library's side streams are folded into the caller's stream (kernels run one at a time,
+ * with the same grids as in normal operation, so a duration is that kernel alone on the chip -- what a roofline
+ * fraction needs).  cf_profile_read synchronises them and returns, for conv tile kind t >= 1 (index 0 = all
+ * contraction launches), the summed launch duration in ms, the summed algorithmic flops (2*M*N*K with the un-padded
+ * K) and the launch count, then clears the records.  cf_conv_tile_name(t) = kernel symbol.
+ * cf_profile_report_json: one row per (layer tag, kernel symbol, grid in work-items = rocprofv3's Grid_Size) over both
+ * classes: "mfma" rows carry algorithmic flops, "hbm" rows algorithmic bytes (each input read once, each output
+ * written once) in `work`.  Environment CF_SERIAL=1 gives the same serialised launch order without the events (the
+ * mode profiles/<round>_ktrace_serial.txt is taken in). */
 int cf_profile_enable(cf_handle* h, int on);
 int cf_profile_read(cf_handle* h, double* ms, double* flops, long long* count, int n);
 const char* cf_conv_tile_name(int tile);
 /* per-layer text table of the last cf_profile_read (layer, tile kind, launches, ms, TFLOP/s) */
 const char* cf_profile_report(const cf_handle* h);
+const char* cf_profile_report_json(const cf_handle* h);
 
 /* single-operator entry points (used by the parity tests; same kernels as the fused paths) ------ */
 /* conv2d on NHWC input (a_mode 0), fused x2-upsample input (a_mode 1) or planar NCHW small-Cin input

@@ -601,3 +601,63 @@ def events_to_voxel(events, num_bins, width, height, normalize=True):
             sd = np.sqrt((vox ** 2).sum() / n - mean ** 2)
             vox = (nz.astype(np.float32) * (vox - mean) / (sd + 1e-8)).astype(np.float32)
     return vox
+
+
+# ----------------------------------------------------------------------------------------------
+# f-3: evaluation metrics -- restated from /root/reference/loss.py
+# ----------------------------------------------------------------------------------------------
+def recon_metrics(rec, tgt):
+    """nn.MSELoss + PSNR(data_range=1)   loss.py:15-24, 316-328 (ReconLoss.evaluate without ssim / lpips)."""
+    mse = ((rec.double() - tgt.double()) ** 2).mean()
+    psnr = 100.0 if mse < 1.0e-10 else 20.0 * math.log10(1.0 / math.sqrt(float(mse)))
+    return float(mse), float(psnr)
+
+
+def flow_metrics(flow_final, gt_flow, gt_img0, gt_img1, flow_valid=None, warp_mode="forward", max_flow=400.0):
+    """FlowL1LossDict.evaluate   loss.py:237-265 -> (photo_loss, epe, 1px, 3px, 5px, out).  Per-pixel gt magnitude
+    (the reference's epe [B,H,W] / mag [B,1,H,W] broadcast only works at batch 1, where it means the same)."""
+    if flow_valid is None:
+        flow_valid = torch.exp(-50 * (warp(gt_img0, gt_flow, warp_mode) - gt_img1) ** 2)       # :241
+    mag = torch.sum(gt_flow ** 2, dim=1, keepdim=True).sqrt()                                    # :243
+    valid = flow_valid * (mag < max_flow).float()                                                # :244
+    photo = (warp(gt_img0, flow_final, warp_mode) - gt_img1).abs().double().mean()              # :247
+    epe = torch.sum(valid * (flow_final - gt_flow) ** 2, dim=1, keepdim=True).sqrt()            # :248
+    out = ((epe > 3.0) & ((epe / mag) > 0.05)).double()                                          # :250
+    sel = valid > 0
+    e = epe[sel].double()
+    return (float(photo), float(e.mean()), float((e > 1).double().mean()), float((e > 3).double().mean()),
+            float((e > 5).double().mean()), float(out[sel].mean() * 100))
+
+
+def fwl_sample_zeros(plane, ix, iy):
+    """grid_sample(bilinear, align_corners=True, padding_mode='zeros') of [B,H,W] planes at pixel coords."""
+    B, H, W = plane.shape
+    x0, y0 = torch.floor(ix), torch.floor(iy)
+    tx, ty = ix - x0, iy - y0
+    out = torch.zeros_like(ix)
+    bidx = torch.arange(B).view(B, 1, 1).expand_as(ix)
+    for dy, wy in ((0, 1 - ty), (1, ty)):
+        for dx, wx in ((0, 1 - tx), (1, tx)):
+            xx, yy = x0 + dx, y0 + dy
+            ok = (xx >= 0) & (xx <= W - 1) & (yy >= 0) & (yy <= H - 1)
+            v = plane[bidx, yy.clamp(0, H - 1).long(), xx.clamp(0, W - 1).long()]
+            out = out + torch.where(ok, v * (wy * wx), torch.zeros_like(v))
+    return out
+
+
+def voxel_warping_flow_loss(voxel, displacement):
+    """loss.py:27-83: channel i of the voxel grid sampled at (x + dx*i/(C-1), y + dy*i/(C-1)), grid normalised by W (not
+    W-1) and sampled with align_corners=True / zeros padding, summed over i; the loss is the variance of that image."""
+    B, C, H, W = voxel.shape
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    xx, yy = xx.float(), yy.float()
+    inc = 1.0 / (C - 1.0)
+    acc = torch.zeros(B, H, W)
+    for i in range(C):
+        r = i * inc
+        gx = (2.0 * (xx + displacement[:, 0] * r)) / W - 1.0
+        gy = (2.0 * (yy + displacement[:, 1] * r)) / H - 1.0
+        ix = ((gx + 1.0) / 2.0) * (W - 1)
+        iy = ((gy + 1.0) / 2.0) * (H - 1)
+        acc = acc + fwl_sample_zeros(voxel[:, i], ix, iy)
+    return float(acc.double().var())

@@ -1,0 +1,83 @@
+"""f-3: evaluation metrics on the device (csrc/metrics.hip behind cista_flow_amd/loss.py) against
+(1) values the reference's loss.py produced (tests/golden/metrics.npz, tools/gen_golden.py) and (2) the CPU oracle on
+fresh inputs at batch > 1.  Reductions run in fp64 on the device and in fp32 in the reference: agreement is to fp32
+rounding of the reference's own sums (asserted 2e-5 relative)."""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import golden_util as gu          # noqa: E402
+import weights_util as wu         # noqa: E402
+
+pytestmark = pytest.mark.gpu
+RT = 2e-5
+
+
+def close(a, b, rt=RT, at=1e-7):
+    return abs(float(a) - float(b)) <= rt * abs(float(b)) + at
+
+
+def test_recon_metrics_golden(gpu):
+    from cista_flow_amd.loss import ReconLoss, PSNR
+    g = gu.load("metrics.npz")
+    rec, tgt = torch.from_numpy(g["rec"]).to(gpu), torch.from_numpy(g["tgt"]).to(gpu)
+    m = ReconLoss(None).evaluate(rec, tgt)
+    assert set(m) == {"mse", "psnr"}
+    assert close(m["mse"], g["mse"]) and abs(m["psnr"] - float(g["psnr"])) < 1e-4
+    assert float(PSNR()(rec, rec)) == 100.0 == float(g["psnr_same"])
+
+
+@pytest.mark.parametrize("mode", ["forward", "backward"])
+def test_flow_metrics_golden(gpu, mode):
+    from cista_flow_amd.loss import FlowL1LossDict
+    from cista_flow_amd.utils.flow_utils import FrameWarp
+    g = gu.load("metrics.npz")
+    t = {k: torch.from_numpy(g[k + "_" + mode]).to(gpu) for k in ("flow", "gt", "img0", "img1", "valid")}
+    L = FlowL1LossDict([t["flow"].shape[2], t["flow"].shape[3]], FrameWarp(mode))
+    keys = ["photo_loss", "epe", "1px", "3px", "5px", "out"]
+    m1 = L.evaluate(t["flow"], {"gt_flow": t["gt"], "gt_img0": t["img0"], "gt_img1": t["img1"], "flow_valid": t["valid"]})
+    m2 = L.evaluate(t["flow"], {"gt_flow": t["gt"], "gt_img0": t["img0"], "gt_img1": t["img1"]})
+    for got, ref in ((m1, g["fm_valid_" + mode]), (m2, g["fm_photo_" + mode])):
+        for k, r in zip(keys, ref):
+            assert close(got[k], r), (mode, k, got[k], float(r))
+
+
+def test_fwl_golden(gpu):
+    from cista_flow_amd.loss import voxel_warping_flow_loss, fwl_metrics
+    g = gu.load("metrics.npz")
+    evs, flow = torch.from_numpy(g["fwl_evs"]).to(gpu), torch.from_numpy(g["fwl_flow"]).to(gpu)
+    # the drivers' expression (test_wo_flow.py:161)
+    fwl = voxel_warping_flow_loss(evs, flow) / voxel_warping_flow_loss(evs, torch.zeros_like(flow))
+    assert close(fwl, g["fwl"][2], 1e-5)
+    m = fwl_metrics(evs, flow).cpu()
+    assert close(m[0], g["fwl"][0], 1e-5) and close(m[1], g["fwl"][1], 1e-5) and close(m[2], g["fwl"][2], 1e-5)
+
+
+def test_metrics_vs_oracle_batched(gpu):
+    """B = 3, ragged size, no validity mask for one call: HIP vs the oracle restatement; plus determinism."""
+    from cista_flow_amd.loss import flow_metrics, fwl_metrics, recon_metrics
+    from oracle import cista_oracle as orc
+    gen = torch.Generator().manual_seed(5)
+    B, H, W = 3, 67, 93
+    flow = 4.0 * torch.randn(B, 2, H, W, generator=gen)
+    gt = flow + torch.randn(B, 2, H, W, generator=gen)
+    gt[1, :, :3] = 1000.0
+    i0 = torch.rand(B, 1, H, W, generator=gen)
+    i1 = (i0 + 0.05 * torch.randn(B, 1, H, W, generator=gen)).clamp(0, 1)
+    for mode in ("forward", "backward"):
+        got = flow_metrics(flow.to(gpu), gt.to(gpu), i0.to(gpu), i1.to(gpu), None, mode)
+        again = flow_metrics(flow.to(gpu), gt.to(gpu), i0.to(gpu), i1.to(gpu), None, mode)
+        assert torch.equal(got, again)
+        ref = orc.flow_metrics(flow, gt, i0, i1, None, mode)
+        for a, b in zip(got.cpu().tolist(), ref):
+            assert close(a, b), (mode, got, ref)
+    evs = wu.synth_events(B, 5, H, W, 99)
+    m = fwl_metrics(evs.to(gpu), flow.to(gpu)).cpu()
+    assert close(m[0], orc.voxel_warping_flow_loss(evs, flow), 1e-5)
+    assert close(m[1], orc.voxel_warping_flow_loss(evs, torch.zeros_like(flow)), 1e-5)
+    r = recon_metrics(i0.to(gpu), i1.to(gpu)).cpu()
+    mse, psnr = orc.recon_metrics(i0, i1)
+    assert close(r[0], mse, 1e-9) and abs(float(r[1]) - psnr) < 1e-9

@@ -286,42 +286,124 @@ def test_eiflow_f16x3_precision_mode(gpu):
     assert worst < 3e-4, worst
 
 
-@pytest.mark.parametrize("H,W,B", [(180, 240, 8), (480, 640, 2)])
-def test_full_size_batch_properties(gpu, H, W, B):
-    """BASELINE configs[1] / configs[3] geometry (full sizes, where the oracle is too slow for the whole batch):
-    size-independent properties of the step.  Sequences are independent, so (a) identical inputs in different
-    batch slots give bit-identical outputs (every kernel indexes its image correctly at full size), (b) a slot's
-    result does not depend on what the other slots hold, (c) re-running is deterministic, and (d) one slot of
-    one frame agrees with the CPU oracle."""
+def _build(kind, H, W, seed, gpu, precision="f32"):
+    from cista_flow_amd.e2v.e2v_model import DCEIFlowCistaNet, ERAFTCistaNet, IDCistaNet
+    cls = {"eiflow": DCEIFlowCistaNet, "eraft": ERAFTCistaNet, "idnet": IDCistaNet}[kind]
+    m = cls(args_for(H, W)).eval()
+    m.precision = precision
+    wu.fill_module(m, seed)
+    m = m.to(gpu)
+    if kind != "idnet":
+        m.event_flownet.return_flow_preds = True          # like the reference: every iteration's up-flow is produced
+    return m
+
+
+def _drive(kind, m, evs, ev_first_old, dev):
+    """The drivers' per-frame loop (test_with_flow.py:120-156) over the voxel grids `evs`: feedback of the prediction,
+    eraft's `evs_old` carry, idnet's next_flow -> flow_init carry.  Returns per-frame (I, flow_final, z, h, preds)."""
+    B, _, H, W = evs[0].shape
+    states, prev, flow_init, old, out = None, torch.zeros(B, 1, H, W, device=dev), None, ev_first_old, []
+    for ev in evs:
+        if kind == "eiflow":
+            I, bf, states = m({"event_voxel": ev, "rec_img0": prev}, states, {})
+        elif kind == "eraft":
+            I, bf, states = m({"event_voxel": ev, "event_voxel_old": old, "rec_img0": prev}, states, {})
+            old = ev
+        else:
+            I, bf, states = m({"event_voxel": ev, "rec_img0": prev}, states, flow_init, {})
+            flow_init = bf["next_flow"]
+        out.append((I, bf["flow_final"], states[1], states[2][0], bf["flow_preds"]))
+        prev = I.clone()
+    return out
+
+
+def _oracle_drive(kind, sd, evs, ev_first_old):
     from oracle import cista_oracle as orc
-    m = build_eiflow(H, W, 4242, gpu)
-    ev0 = wu.synth_events(1, 5, H, W, 9100)
-    ev1 = wu.synth_events(1, 5, H, W, 9101)
-    evA = torch.cat([ev0] * B, 0).to(gpu)                    # all slots equal
-    evB = torch.cat([ev0] + [ev1] * (B - 1), 0).to(gpu)      # slot 0 equal, the rest different
-    prev = torch.zeros(B, 1, H, W, device=gpu)
+    B, _, H, W = evs[0].shape
+    states, prev, flow_init, old, out = None, torch.zeros(B, 1, H, W), None, ev_first_old, []
+    for ev in evs:
+        if kind == "eiflow":
+            I, bf, states = orc.eiflow_step(sd, {"event_voxel": ev, "rec_img0": prev}, states)
+        elif kind == "eraft":
+            I, bf, states = orc.eraft_step(sd, {"event_voxel": ev, "event_voxel_old": old, "rec_img0": prev}, states)
+            old = ev
+        else:
+            I, bf, states = orc.idnet_step(sd, {"event_voxel": ev, "rec_img0": prev}, states, flow_init)
+            flow_init = bf["next_flow"]
+        out.append((I, bf["flow_final"], states[1], states[2][0], bf["flow_preds"]))
+        prev = I.clone()
+    return out
+
+
+FULL_SIZE = [("eiflow", 180, 240, 8, "f32"),     # BASELINE configs[1]
+             ("eraft", 180, 240, 8, "f32"),      # configs[2]
+             ("eiflow", 480, 640, 4, "f32"),     # configs[3]: 32 sequences over 8 GPUs = 4 per GPU
+             ("idnet", 260, 346, 16, "f32"),     # configs[4] geometry in exact fp32
+             ("idnet", 260, 346, 16, "f16")]     # configs[4] as named: f16 MFMA products
+
+
+@pytest.mark.parametrize("kind,H,W,B,prec", FULL_SIZE, ids=["%s-%dx%d-B%d-%s" % c for c in FULL_SIZE])
+def test_full_size_batch_properties(gpu, kind, H, W, B, prec):
+    """Every BASELINE config at its FULL size and per-GPU batch (where the oracle is too slow for the whole batch):
+    size-independent properties of the step.  Sequences are independent, so (a) identical inputs in different batch
+    slots give bit-identical outputs (every kernel -- tiles, convex up-sampling, deblur -- indexes its image correctly
+    at this grid size), (b) a slot's result does not depend on what the other slots hold, (c) re-running is
+    deterministic, and (d) slot 0 of a two-frame recurrent sequence agrees with the CPU oracle run at B=1."""
+    m = _build(kind, H, W, 4242, gpu, prec)
+    ev0 = [wu.synth_events(1, 5, H, W, 9100 + t) for t in range(2)]
+    ev1 = [wu.synth_events(1, 5, H, W, 9200 + t) for t in range(2)]
+    old0, old1 = wu.synth_events(1, 5, H, W, 9300), wu.synth_events(1, 5, H, W, 9301)
+    evA = [torch.cat([e] * B, 0).to(gpu) for e in ev0]                           # all slots equal
+    evB = [torch.cat([a] + [b] * (B - 1), 0).to(gpu) for a, b in zip(ev0, ev1)]  # slot 0 equal, the rest different
+    oldA = torch.cat([old0] * B, 0).to(gpu)
+    oldB = torch.cat([old0] + [old1] * (B - 1), 0).to(gpu)
     with torch.no_grad():
-        IA1, bfA1, stA1 = m({"event_voxel": evA, "rec_img0": prev}, None, {})
-        IA2, bfA2, stA2 = m({"event_voxel": evA, "rec_img0": IA1.clone()}, stA1, {})
-        IB1, bfB1, stB1 = m({"event_voxel": evB, "rec_img0": prev}, None, {})
-        IA1r, bfA1r, _ = m({"event_voxel": evA, "rec_img0": prev}, None, {})
+        A = _drive(kind, m, evA, oldA, gpu)
+        Bo = _drive(kind, m, evB, oldB, gpu)
+        A2 = _drive(kind, m, evA, oldA, gpu)
     torch.cuda.synchronize()
-    assert torch.isfinite(IA2).all()
-    for k in range(1, B):                                    # (a), on both the cold and the recurrent frame
-        assert torch.equal(IA1[k], IA1[0]) and torch.equal(IA2[k], IA2[0]), k
-        assert torch.equal(bfA2["flow_final"][k], bfA2["flow_final"][0]), k
-        assert torch.equal(stA2[1][k], stA2[1][0]) and torch.equal(stA2[2][0][k], stA2[2][0][0]), k
-    assert torch.equal(IB1[0], IA1[0]) and torch.equal(bfB1["flow_final"][0], bfA1["flow_final"][0])   # (b)
-    assert not torch.equal(IB1[1], IA1[1])
-    assert torch.equal(IA1r, IA1) and torch.equal(bfA1r["flow_final"], bfA1["flow_final"])                 # (c)
-    # (d) slot 0, two frames, against the oracle at B=1
+    for t in range(2):
+        I, flow, z, hh, preds = A[t]
+        assert torch.isfinite(I).all() and torch.isfinite(flow).all()
+        for k in range(1, B):                                                    # (a), cold and recurrent frame
+            assert torch.equal(I[k], I[0]) and torch.equal(flow[k], flow[0]), (t, k)
+            assert torch.equal(z[k], z[0]) and torch.equal(hh[k], hh[0]), (t, k)
+            for pr in preds:
+                assert torch.equal(pr[k], pr[0]), (t, k)
+        assert torch.equal(Bo[t][0][0], I[0]) and torch.equal(Bo[t][1][0], flow[0]) and torch.equal(Bo[t][2][0], z[0])   # (b)
+        assert not torch.equal(Bo[t][0][1], I[1])
+        assert torch.equal(A2[t][0], I) and torch.equal(A2[t][1], flow) and torch.equal(A2[t][2], z)                      # (c)
+    # (d) slot 0 against the oracle at B=1 (fp32 modes: the 2e-4 regression bar; plain f16 products: the 1e-2 this
+    # reduced-precision mode is documented with, DESIGN.md section 7)
     sd = {k: v.cpu() for k, v in m.state_dict().items()}
     with torch.no_grad():
-        I1, bf1, st1 = orc.eiflow_step(sd, {"event_voxel": ev0, "rec_img0": torch.zeros(1, 1, H, W)}, None)
-        I2, bf2, st2 = orc.eiflow_step(sd, {"event_voxel": ev0, "rec_img0": I1.clone()}, st1)
-    assert gu.rel_err(IA1[:1].cpu(), I1) < TOL and gu.rel_err(IA2[:1].cpu(), I2) < TOL
-    assert gu.rel_err(bfA2["flow_final"][:1].cpu(), bf2["flow_final"]) < TOL
-    assert gu.rel_err(stA2[1][:1].cpu(), st2[1]) < TOL
+        O = _oracle_drive(kind, sd, ev0, old0)
+    tol = TOL if prec == "f32" else 1e-2
+    for t in range(2):
+        for name, got, ref in (("I", A[t][0], O[t][0]), ("flow", A[t][1], O[t][1]), ("z", A[t][2], O[t][2]), ("h", A[t][3], O[t][3])):
+            assert gu.rel_err(got[:1].cpu(), ref) < tol, (t, name)
+        assert len(A[t][4]) == len(O[t][4])
+        for a, b in zip(A[t][4], O[t][4]):
+            assert gu.rel_err(a[:1].cpu(), b) < tol, t
+
+
+def test_eiflow_fullstate_golden(gpu):
+    """Every element of the sparse code after the 4-frame eiflow_100x124 sequence against the reference's own tensor
+    (the per-frame fixtures only keep a strided 1/36 probe of each state)."""
+    g = gu.load("eiflow_100x124_fullstate.npz")
+    H, W, B, frames, seed = [int(v) for v in g["meta"]]
+    m = build_eiflow(H, W, seed, gpu)
+    evs = [wu.synth_events(B, 5, H, W, seed * 1000 + t).to(gpu) for t in range(frames)]
+    with torch.no_grad():
+        out = _drive("eiflow", m, evs, None, gpu)
+    assert gu.rel_err(out[-1][2].cpu(), g["z_full"]) < TOL
+    assert gu.rel_err(out[-1][3].cpu(), g["h_full"]) < TOL
+    # element-wise, not only relative to the tensor maximum: the soft threshold produces exact zeros, and an element
+    # the reference zeroed must be (numerically) zero here too
+    ref = torch.from_numpy(g["z_full"])
+    got = out[-1][2].cpu()
+    assert ((got - ref).abs() <= TOL * ref.abs().max()).all()
+    assert ((ref == 0) == (got == 0)).float().mean() > 0.999
 
 
 def _idnet_sequence_errors(gpu, name, precision):

@@ -141,3 +141,37 @@ def test_state_dict_layout_matches_reference():
     m.load_state_dict(sd, strict=True)
     blocks = m.cista_net.lista_blocks
     assert all(blocks[i].Lambda.data_ptr() == blocks[0].Lambda.data_ptr() for i in range(5))
+
+
+def test_metrics_golden():
+    """f-3: the oracle's restatement of loss.py against values the reference itself produced (tools/gen_golden.py)."""
+    g = gu.load("metrics.npz")
+    mse, psnr = orc.recon_metrics(torch.from_numpy(g["rec"]), torch.from_numpy(g["tgt"]))
+    assert abs(mse - float(g["mse"])) < 1e-6 * float(g["mse"]) + 1e-12
+    assert abs(psnr - float(g["psnr"])) < 1e-4
+    assert orc.recon_metrics(torch.from_numpy(g["rec"]), torch.from_numpy(g["rec"]))[1] == float(g["psnr_same"]) == 100.0
+    for mode in ("forward", "backward"):
+        t = {k: torch.from_numpy(g[k + "_" + mode]) for k in ("flow", "gt", "img0", "img1", "valid")}
+        m1 = orc.flow_metrics(t["flow"], t["gt"], t["img0"], t["img1"], t["valid"], mode)
+        m2 = orc.flow_metrics(t["flow"], t["gt"], t["img0"], t["img1"], None, mode)
+        for got, ref in ((m1, g["fm_valid_" + mode]), (m2, g["fm_photo_" + mode])):
+            for a, b in zip(got, ref):
+                assert abs(a - float(b)) <= 2e-5 * abs(float(b)) + 1e-7, (mode, got, ref)
+    v1 = orc.voxel_warping_flow_loss(torch.from_numpy(g["fwl_evs"]), torch.from_numpy(g["fwl_flow"]))
+    v0 = orc.voxel_warping_flow_loss(torch.from_numpy(g["fwl_evs"]), torch.zeros_like(torch.from_numpy(g["fwl_flow"])))
+    assert abs(v1 - g["fwl"][0]) < 1e-5 * g["fwl"][0] and abs(v0 - g["fwl"][1]) < 1e-5 * g["fwl"][1]
+    assert abs(v1 / v0 - g["fwl"][2]) < 1e-5
+
+
+def test_fullstate_golden():
+    """The un-strided sparse code of the eiflow_100x124 sequence (every element of states[1] after 4 frames)."""
+    g = gu.load("eiflow_100x124_fullstate.npz")
+    H, W, B, frames, seed = [int(v) for v in g["meta"]]
+    sd = wu.make_state_dict(gu.layout("eiflow_state_dict_layout.json"), seed)
+    states, prev = None, torch.zeros(B, 1, H, W)
+    for t in range(frames):
+        ev = wu.synth_events(B, 5, H, W, seed * 1000 + t)
+        I, bf, states = orc.eiflow_step(sd, {"event_voxel": ev, "rec_img0": prev}, states)
+        prev = I.clone()
+    assert gu.rel_err(states[1], g["z_full"]) < 5e-5
+    assert gu.rel_err(states[2][0], g["h_full"]) < 5e-5

@@ -202,6 +202,87 @@ def run_warp(ref_flow, name):
     print(name)
 
 
+def run_fullstate(ref_model, H, W, B, frames, seed, name):
+    """One UN-STRIDED sparse-code tensor (states[1] after the last frame) of the eiflow_100x124 sequence: the other
+    fixtures keep every 4th channel / 3rd row / 3rd column of the states only."""
+    from weights_util import fill_module, synth_events
+    torch.manual_seed(0)
+    model = ref_model.DCEIFlowCistaNet(ns(H, W)).eval()
+    fill_module(model, seed)
+    states, prev = None, torch.zeros(B, 1, H, W)
+    with torch.no_grad():
+        for t in range(frames):
+            ev = synth_events(B, 5, H, W, seed * 1000 + t)
+            I, bf, states = model({"event_voxel": ev, "rec_img0": prev}, states, {})
+            prev = I.clone()
+    out = {"meta": np.array([H, W, B, frames, seed], dtype=np.int64), "z_full": states[1].numpy(),
+           "h_full": states[2][0].numpy()}
+    np.savez_compressed(os.path.join(GOLD, name), **out)
+    print(name, out["z_full"].shape)
+
+
+def run_metrics(name):
+    """f-3: the evaluation metrics of loss.py, run from the reference itself.  loss.py's two third-party
+    imports (utils.evaluate -> lpips / skimage, pytorch_msssim) are not installed here and are stubbed: SSIM and LPIPS
+    are therefore NOT part of the fixture (nor of the build); everything else is pure torch."""
+    ev_mod = types.ModuleType("utils.evaluate")
+
+    class PerceptualLoss(object):
+        def __init__(self, *a, **k):
+            pass
+
+    ev_mod.PerceptualLoss = PerceptualLoss
+    sys.modules["utils.evaluate"] = ev_mod
+    ms = types.ModuleType("pytorch_msssim")
+
+    class SSIM(object):
+        def __init__(self, *a, **k):
+            pass
+
+    ms.SSIM = SSIM
+    sys.modules["pytorch_msssim"] = ms
+    import loss as ref_loss                      # noqa: E402
+    import utils.flow_utils as ref_flow          # noqa: E402
+    from weights_util import synth_events
+    g = torch.Generator().manual_seed(77)
+    B, H, W = 2, 100, 124
+    out = {"meta": np.array([B, H, W], dtype=np.int64)}
+    rec = torch.rand(B, 1, H, W, generator=g)
+    tgt = (rec + 0.05 * torch.randn(B, 1, H, W, generator=g)).clamp(0, 1)
+    out["rec"], out["tgt"] = rec.numpy(), tgt.numpy()
+    out["mse"] = np.float64(torch.nn.MSELoss()(rec, tgt).item())                 # ReconLoss.evaluate, loss.py:318
+    out["psnr"] = np.float64(float(ref_loss.PSNR(data_range=1)(rec, tgt)))       # loss.py:15-24
+    out["psnr_same"] = np.float64(float(ref_loss.PSNR(data_range=1)(rec, rec)))  # the mse < 1e-10 branch -> 100
+    # FlowL1LossDict.evaluate only runs at batch 1 (loss.py:250 divides epe [B,H,W] by mag [B,1,H,W], which broadcasts
+    # to [B,B,H,W] and then fails the mask at B > 1; the drivers evaluate with batch 1): fixtures are B = 1
+    for mode in ("forward", "backward"):
+        fw = ref_flow.FrameWarp(mode=mode)
+        L = ref_loss.FlowL1LossDict([H, W], fw)
+        flow = 3.0 * torch.randn(1, 2, H, W, generator=g)
+        gt = flow + 1.5 * torch.randn(1, 2, H, W, generator=g)
+        gt[0, :, 5:9, 7:20] = 500.0            # beyond max_flow = 400 -> invalid
+        gt[0, :, 50:60, 30:40] *= 0.01         # tiny magnitudes: epe / mag large
+        img0 = torch.rand(1, 1, H, W, generator=g)
+        img1 = (img0 + 0.1 * torch.randn(1, 1, H, W, generator=g)).clamp(0, 1)
+        valid = (torch.rand(1, 1, H, W, generator=g) > 0.2).float()
+        out["flow_" + mode], out["gt_" + mode] = flow.numpy(), gt.numpy()
+        out["img0_" + mode], out["img1_" + mode], out["valid_" + mode] = img0.numpy(), img1.numpy(), valid.numpy()
+        keys = ["photo_loss", "epe", "1px", "3px", "5px", "out"]
+        m1 = L.evaluate(flow, {"gt_flow": gt, "gt_img0": img0, "gt_img1": img1, "flow_valid": valid})   # loss.py:237-265
+        m2 = L.evaluate(flow, {"gt_flow": gt, "gt_img0": img0, "gt_img1": img1})                        # photometric validity
+        out["fm_valid_" + mode] = np.array([m1[k] for k in keys], dtype=np.float64)
+        out["fm_photo_" + mode] = np.array([m2[k] for k in keys], dtype=np.float64)
+    # FWL (test_wo_flow.py:161): variance of the flow-warped event image over that of the un-warped one
+    evs = synth_events(B, 5, H, W, 4711)
+    flow = 2.0 * torch.randn(B, 2, H, W, generator=g)
+    v1 = ref_loss.voxel_warping_flow_loss(evs, flow)                 # loss.py:27-83
+    v0 = ref_loss.voxel_warping_flow_loss(evs, torch.zeros_like(flow))
+    out["fwl_evs"], out["fwl_flow"] = evs.numpy(), flow.numpy()
+    out["fwl"] = np.array([float(v1), float(v0), float(v1 / v0)], dtype=np.float64)
+    np.savez_compressed(os.path.join(GOLD, name), **out)
+    print(name, {k: out[k] for k in ("mse", "psnr", "fwl")}, out["fm_valid_forward"], out["fm_photo_backward"])
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ref_model, ref_flow = import_reference()
@@ -218,8 +299,9 @@ def main():
     d = ref_model.IDCistaNet(ns(180, 240))
     with open(os.path.join(GOLD, "idnet_state_dict_layout.json"), "w") as f:
         json.dump([[k, list(v.shape)] for k, v in d.state_dict().items()], f)
-    if "--only-new" in sys.argv:
-        run_events("events.npz")
+    if "--only-new" in sys.argv:       # round 2 additions only (the round-1 fixtures stay byte-identical)
+        run_metrics("metrics.npz")
+        run_fullstate(ref_model, 100, 124, 2, 4, 21, "eiflow_100x124_fullstate.npz")
         return
     run_events("events.npz")
     run_idnet(ref_model, 68, 92, 2, 3, 41, "idnet_68x92.npz")
@@ -232,6 +314,8 @@ def main():
     run_eiflow(ref_model, 100, 124, 2, 4, 21, "forward", "eiflow_100x124.npz", keep_inter=True)
     run_eiflow(ref_model, 128, 136, 1, 2, 22, "backward", "eiflow_128x136_bw.npz")
     run_eiflow(ref_model, 180, 240, 1, 2, 23, "forward", "eiflow_180x240.npz")
+    run_metrics("metrics.npz")
+    run_fullstate(ref_model, 100, 124, 2, 4, 21, "eiflow_100x124_fullstate.npz")
 
 
 if __name__ == "__main__":
