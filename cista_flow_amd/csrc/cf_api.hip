@@ -159,11 +159,27 @@ struct cf_handle {
         return e;
     }
 
+    // hipGraph replay of cf_step (step_dispatch)
+    struct GraphKey {
+        const void* p[20];
+        bool operator==(const GraphKey& o) const { return memcmp(p, o.p, sizeof(p)) == 0; }
+    };
+    struct GraphEntry { GraphKey key; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; unsigned long tick = 0; };
+    std::vector<GraphEntry> graphs;
+    std::vector<GraphKey> seen;
+    bool graph_on = false;
+    unsigned long graph_tick = 0;
+    long long graph_captures = 0, graph_replays = 0;
+    hipStream_t gstream = nullptr;               // stands in for the (uncapturable) legacy stream
+    hipEvent_t ev_g[2] = {nullptr, nullptr};
+
     int fail(int code, const std::string& msg) {
         err = msg;
         return code;
     }
 };
+
+static void graph_clear(cf_handle* h);
 
 #define CF_HIP(h, expr)                                                                              \
     do {                                                                                             \
@@ -549,6 +565,7 @@ extern "C" int cf_load_weights(cf_handle* h, const char* name, const void* dev_p
 extern "C" int cf_finalize_weights(cf_handle* h, void* stream) {
     if (!h) return CF_ERR_ARG;
     h->fmap2_valid = false;       // cached ERAFT feature maps belong to the old weights
+    graph_clear(h);               // captured steps point at the old packed weights
     hipStream_t st = static_cast<hipStream_t>(stream);
     DeviceGuard dg(h->cfg.device);
     if (!dg.ok) return h->fail(CF_ERR_HIP, "hipSetDevice failed");
@@ -781,6 +798,12 @@ extern "C" int cf_create(cf_handle** out, const cf_config* cfg) {
     ok = ok && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&h->ev_upf, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&h->ev_g[0], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&h->ev_g[1], hipEventDisableTiming) == hipSuccess;
+    // CF_GRAPH=0|1 overrides the default (host time per step)
+    h->graph_on = true;
+    if (const char* e = getenv("CF_GRAPH")) h->graph_on = atoi(e) != 0;
     if (!ok) {
         (void)hipFree(h->arena_mem);
         delete h;
@@ -798,6 +821,10 @@ extern "C" int cf_create(cf_handle** out, const cf_config* cfg) {
 extern "C" void cf_destroy(cf_handle* h) {
     if (!h) return;
     DeviceGuard dg(h->cfg.device);
+    if (h->gstream) (void)hipStreamSynchronize(h->gstream);
+    graph_clear(h);
+    if (h->gstream) (void)hipStreamDestroy(h->gstream);
+    for (int i = 0; i < 2; ++i) if (h->ev_g[i]) (void)hipEventDestroy(h->ev_g[i]);
     for (void* p : h->owned) (void)hipFree(p);
     if (h->arena_mem) (void)hipFree(h->arena_mem);
     for (int i = 0; i < 3; ++i) {
@@ -1167,8 +1194,20 @@ static int encoder_forward(cf_handle* h, const std::string& pre, bool bn, const 
 // ERAFT.forward  ERAFT/eraft.py:114-178 shares this graph: ev = image1 (old voxel grid), img = image2 (new voxel
 // grid); fnet runs on both (instance norm is per sample, so the reference's batch concat equals two runs),
 // cnet on image2, no fusion, no emap branch, 12 iterations, learned convex up-sampling.
+// ERAFT host-side state of the feature reuse: decided (and the two feature buffers swapped) BEFORE the kernels are
+// issued, so that a captured graph of the step can be keyed on it; eraft_done() marks the buffers valid afterwards.
+static bool eraft_begin(cf_handle* h) {
+    if (h->cfg.mode != CF_MODE_ERAFT) return false;
+    const bool reuse = h->reuse_next && h->fmap2_valid;
+    h->reuse_next = false;
+    h->fmap2_valid = false;
+    if (reuse) std::swap(h->fmap1, h->pfmap2);      // fnet(in0) == fnet(previous in1): same kernels on the same bytes
+    return reuse;
+}
+static void eraft_done(cf_handle* h) { h->fmap2_valid = h->cfg.mode == CF_MODE_ERAFT; }
+
 static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const float* flow_init, float* flow_final,
-                          float* flow_low, float* flow_preds, int* flag, hipStream_t st) {
+                          float* flow_low, float* flow_preds, int* flag, hipStream_t st, bool reuse) {
     const int B = h->B, h8 = h->h8, w8 = h->w8;
     const long N = h->N;
     const bool eraft = h->cfg.mode == CF_MODE_ERAFT;
@@ -1192,11 +1231,7 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
         if ((rc = encoder_forward(h, "event_flownet.fnet", false, img, 1, 2.f, -1.f, h->fmap1, nullptr, 1, sx0))) return rc;
         if ((rc = encoder_forward(h, "event_flownet.cnet", true, img, 1, 2.f, -1.f, h->net, h->inp, 2, sx1))) return rc;
     } else {
-        const bool reuse = h->reuse_next && h->fmap2_valid;
-        h->reuse_next = false;
-        h->fmap2_valid = false;
         if (reuse) {
-            std::swap(h->fmap1, h->pfmap2);      // fnet(in0) == fnet(previous in1): same kernels on the same bytes
             if ((rc = encoder_forward(h, "event_flownet.fnet", false, img, bins, 1.f, 0.f, h->pfmap2, nullptr, 1, st))) return rc;
         } else {
             if ((rc = encoder_forward(h, "event_flownet.fnet", false, ev, bins, 1.f, 0.f, h->fmap1, nullptr, 0, st))) return rc;
@@ -1356,7 +1391,6 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
         // flow_init of the returned dict = coords1 - coords0 at 1/8 resolution (DCEIFlow.py:297)
         { PROF(h, st, "flow_low", 16.0 * B * N); CF_HIP(h, launch_upflow(h->coords1, B, h8, w8, 1, flow_low, nullptr, 0, 0, 0, 0, nullptr, st)); }
     }
-    h->fmap2_valid = eraft;
     jg.disarm();
     return CF_OK;
 }
@@ -1464,7 +1498,10 @@ extern "C" int cf_flow_forward(cf_handle* h, const float* in0, const float* in1,
     if (h->cfg.mode == CF_MODE_IDNET)   // flow_low = next_flow (padded), flow_preds = {flow_total, delta_flow}
         return idnet_forward(h, in0, flow_init, flow_final, flow_low, flow_preds, h->flag, static_cast<hipStream_t>(stream));
     if (!in1) return h->fail(CF_ERR_ARG, "cf_flow_forward: null pointer");
-    return eiflow_forward(h, in0, in1, flow_init, flow_final, flow_low, flow_preds, h->flag, static_cast<hipStream_t>(stream));
+    const bool reuse = eraft_begin(h);
+    const int rc = eiflow_forward(h, in0, in1, flow_init, flow_final, flow_low, flow_preds, h->flag, static_cast<hipStream_t>(stream), reuse);
+    if (rc == CF_OK) eraft_done(h);
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1476,6 +1513,171 @@ extern "C" int cf_flow_forward(cf_handle* h, const float* in0, const float* in1,
 extern "C" int cf_hint_prev_grid(cf_handle* h, int same_as_previous_in1) {
     if (!h) return CF_ERR_ARG;
     h->reuse_next = same_as_previous_in1 != 0 && h->cfg.mode == CF_MODE_ERAFT;
+    return CF_OK;
+}
+
+struct StepArgs {
+    const float *in0, *in1, *rec_img0, *flow_init, *gt_flow, *c_prev, *z_prev, *h_prev, *cc_prev;
+    float *I_out, *flow_final, *flow_low, *flow_preds, *z_warped_out, *c_out, *z_out, *h_out, *cc_out;
+};
+
+// everything cf_step puts on the stream (no host-side state changes: those are eraft_begin / eraft_done)
+static int step_body(cf_handle* h, const StepArgs& a, bool reuse, hipStream_t st) {
+    int rc;
+    h->phase_mark(0, st);
+    // flow estimation from E_0^1 and the previous reconstruction (e2v_model.py:170-174)
+    if (h->cfg.mode == CF_MODE_IDNET) {
+        if ((rc = idnet_forward(h, a.in0, a.flow_init, a.flow_final, a.flow_low, a.flow_preds, h->flag, st))) return rc;
+    } else if ((rc = eiflow_forward(h, a.in0, a.in1, a.flow_init, a.flow_final, a.flow_low, a.flow_preds, h->flag, st, reuse))) {
+        return rc;
+    }
+    h->phase_mark(2, st);
+    const float* flow = a.flow_final;
+    if (a.gt_flow) {   // e2v_model.py:181-182
+        flow = a.gt_flow;
+        { PROF(h, st, "any_nonzero", 8.0 * h->B * h->H * h->W); CF_HIP(h, launch_any_nonzero(a.gt_flow, (long)h->B * 2 * h->H * h->W, h->flag, st)); }
+    }
+    const int bwd = h->cfg.warp_mode == CF_WARP_BACKWARD ? 1 : 0;
+    const long HW = (long)h->H * h->W, hw = (long)h->h * h->w;
+    const int c2 = 2 * h->bc;
+    // `if not flow_final.any()` -> device flag; flag == 0 makes the warps pass-through copies (:184-191)
+    const float* zin = nullptr;
+    {
+        float* zw = a.z_prev ? (a.z_warped_out ? a.z_warped_out : h->zwarp) : nullptr;
+        // image warp (full resolution) and sparse-code warp (half resolution, flow resampled on the fly) in one launch
+        PROF(h, st, a.z_prev ? "warp.I+Z" : "warp.I", 16.0 * h->B * HW + (a.z_prev ? 4.0 * h->B * hw * (2 * c2 + 2) : 0.0));
+        CF_HIP(h, launch_warp2(a.rec_img0, 1, HW, h->warpedI, 1, HW, 1, h->H, h->W, a.z_prev, c2, hw * c2, zw, c2, hw * c2, c2, h->h, h->w,
+                               flow, h->H, h->W, h->B, bwd, h->flag, st));
+        zin = zw;
+    }
+    // CISTA consumes the current voxel grid: in0 for eiflow, in1 (= image2) for eraft (e2v_model.py:194,246)
+    const float* ev_now = h->cfg.mode == CF_MODE_ERAFT ? a.in1 : a.in0;
+    rc = cista_forward(h, ev_now, h->warpedI, a.c_prev, zin, a.h_prev, a.cc_prev, a.I_out, a.c_out, a.z_out, a.h_out, a.cc_out, st);
+    h->phase_mark(3, st);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// hipGraph replay of cf_step.  A step is ~250-400 launches over up to four streams (2 ms of host time); every pointer
+// it touches is either the handle's own (fixed) or one of the 18 caller pointers.  PyTorch's caching allocator hands a
+// steady per-frame loop the same few blocks again and again, so the step is captured per DISTINCT pointer tuple
+// (the second time a tuple is seen -- a tuple that never repeats never pays for a capture) and replayed on a hit:
+// the same kernels with the same arguments, i.e. bit-identical results.  LRU of GRAPH_CAP executables; cleared
+// whenever the packed weights are rebuilt.  Off while profiling / CF_PHASES / CF_SERIAL, and when the caller's stream
+// is itself being captured (the launches then simply join the caller's capture).
+// ---------------------------------------------------------------------------------------------
+static constexpr size_t GRAPH_CAP = 24, SEEN_CAP = 64;
+
+static void graph_clear(cf_handle* h) {
+    for (auto& g : h->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    h->graphs.clear();
+    h->seen.clear();
+}
+
+extern "C" int cf_graph_enable(cf_handle* h, int on) {
+    if (!h) return CF_ERR_ARG;
+    h->graph_on = on != 0;
+    if (!h->graph_on) graph_clear(h);
+    return CF_OK;
+}
+
+// replays / captures / runs eagerly; returns CF_OK or an error code
+static int step_dispatch(cf_handle* h, const StepArgs& a, bool reuse, hipStream_t st) {
+    bool use = h->graph_on && !h->prof && !h->phases && !h->serial;
+    if (use && st) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) use = false;
+        (void)hipGetLastError();
+    }
+    if (!use) return step_body(h, a, reuse, st);
+    cf_handle::GraphKey key;
+    const void* ptrs[18] = {a.in0, a.in1, a.rec_img0, a.flow_init, a.gt_flow, a.c_prev, a.z_prev, a.h_prev, a.cc_prev, a.I_out,
+                            a.flow_final, a.flow_low, a.flow_preds, a.z_warped_out, a.c_out, a.z_out, a.h_out, a.cc_out};
+    for (int i = 0; i < 18; ++i) key.p[i] = ptrs[i];
+    key.p[18] = h->fmap1;                       // ERAFT: which of the two feature buffers is "old" this frame
+    key.p[19] = reinterpret_cast<const void*>(static_cast<uintptr_t>(reuse ? 1 : 0));
+    ++h->graph_tick;
+    cf_handle::GraphEntry* hit = nullptr;
+    for (auto& g : h->graphs)
+        if (g.key == key) { hit = &g; break; }
+    // the legacy (null) stream cannot be captured or replayed into: use the library's own stream, fenced by events
+    hipStream_t run = st ? st : h->gstream;
+    auto fence_in = [&]() -> int {
+        if (run == st) return CF_OK;
+        CF_HIP(h, hipEventRecord(h->ev_g[0], st));
+        CF_HIP(h, hipStreamWaitEvent(run, h->ev_g[0], 0));
+        return CF_OK;
+    };
+    auto fence_out = [&]() -> int {
+        if (run == st) return CF_OK;
+        CF_HIP(h, hipEventRecord(h->ev_g[1], run));
+        CF_HIP(h, hipStreamWaitEvent(st, h->ev_g[1], 0));
+        return CF_OK;
+    };
+    if (!hit) {
+        bool seen_before = false;
+        for (auto& k : h->seen)
+            if (k == key) { seen_before = true; break; }
+        if (!seen_before) {
+            if (h->seen.size() >= SEEN_CAP) h->seen.erase(h->seen.begin());
+            h->seen.push_back(key);
+            return step_body(h, a, reuse, st);
+        }
+        // second sighting of this pointer tuple: capture the step
+        int rc = fence_in();
+        if (rc != CF_OK) return rc;
+        if (hipStreamBeginCapture(run, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            (void)hipGetLastError();
+            h->graph_on = false;               // capture unsupported here: stay eager from now on
+            return step_body(h, a, reuse, st);
+        }
+        rc = step_body(h, a, reuse, run);
+        hipGraph_t graph = nullptr;
+        const hipError_t ee = hipStreamEndCapture(run, &graph);
+        if (rc != CF_OK || ee != hipSuccess || !graph) {
+            if (graph) (void)hipGraphDestroy(graph);
+            (void)hipGetLastError();
+            h->graph_on = false;
+            if (rc != CF_OK) return rc;
+            return step_body(h, a, reuse, st);     // nothing of the failed capture ran: issue the step eagerly
+        }
+        hipGraphExec_t exec = nullptr;
+        if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess || !exec) {
+            (void)hipGraphDestroy(graph);
+            (void)hipGetLastError();
+            h->graph_on = false;
+            return step_body(h, a, reuse, st);
+        }
+        if (h->graphs.size() >= GRAPH_CAP) {      // evict the least recently used executable
+            size_t lru = 0;
+            for (size_t i = 1; i < h->graphs.size(); ++i)
+                if (h->graphs[i].tick < h->graphs[lru].tick) lru = i;
+            (void)hipGraphExecDestroy(h->graphs[lru].exec);
+            (void)hipGraphDestroy(h->graphs[lru].graph);
+            h->graphs.erase(h->graphs.begin() + (long)lru);
+        }
+        cf_handle::GraphEntry e;
+        e.key = key; e.graph = graph; e.exec = exec; e.tick = h->graph_tick;
+        h->graphs.push_back(e);
+        hit = &h->graphs.back();
+        ++h->graph_captures;
+    } else {
+        const int rc = fence_in();
+        if (rc != CF_OK) return rc;
+    }
+    hit->tick = h->graph_tick;
+    CF_HIP(h, hipGraphLaunch(hit->exec, run));
+    ++h->graph_replays;
+    return fence_out();
+}
+
+// counters for tests / tools: {captures, replays, cached executables}
+extern "C" int cf_graph_stats(const cf_handle* h, long long* out3) {
+    if (!h || !out3) return CF_ERR_ARG;
+    out3[0] = h->graph_captures; out3[1] = h->graph_replays; out3[2] = (long long)h->graphs.size();
     return CF_OK;
 }
 
@@ -1494,36 +1696,12 @@ extern "C" int cf_step(cf_handle* h, const float* in0, const float* in1, const f
     hipStream_t st = static_cast<hipStream_t>(stream);
     DeviceGuard dg(h->cfg.device);
     if (!dg.ok) return h->fail(CF_ERR_HIP, "hipSetDevice failed");
-    int rc;
     h->phase_collect();
-    h->phase_mark(0, st);
-    // flow estimation from E_0^1 and the previous reconstruction (e2v_model.py:170-174)
-    if (h->cfg.mode == CF_MODE_IDNET) {
-        if ((rc = idnet_forward(h, in0, flow_init, flow_final, flow_low, flow_preds, h->flag, st))) return rc;
-    } else if ((rc = eiflow_forward(h, in0, in1, flow_init, flow_final, flow_low, flow_preds, h->flag, st))) {
-        return rc;
-    }
-    h->phase_mark(2, st);
-    const float* flow = flow_final;
-    if (gt_flow) {   // e2v_model.py:181-182
-        flow = gt_flow;
-        { PROF(h, st, "any_nonzero", 8.0 * h->B * h->H * h->W); CF_HIP(h, launch_any_nonzero(gt_flow, (long)h->B * 2 * h->H * h->W, h->flag, st)); }
-    }
-    const int bwd = h->cfg.warp_mode == CF_WARP_BACKWARD ? 1 : 0;
-    const long HW = (long)h->H * h->W, hw = (long)h->h * h->w;
-    const int c2 = 2 * h->bc;
-    // `if not flow_final.any()` -> device flag; flag == 0 makes the warps pass-through copies (:184-191)
-    { PROF(h, st, "warp.I", 16.0 * h->B * HW); CF_HIP(h, launch_warp(rec_img0, 1, HW, flow, h->H, h->W, h->warpedI, 1, HW, h->B, 1, h->H, h->W, bwd, h->flag, st)); }
-    const float* zin = nullptr;
-    if (z_prev) {
-        float* zw = z_warped_out ? z_warped_out : h->zwarp;
-        { PROF(h, st, "warp.Z", 4.0 * h->B * hw * (2 * c2 + 2)); CF_HIP(h, launch_warp(z_prev, c2, hw * c2, flow, h->H, h->W, zw, c2, hw * c2, h->B, c2, h->h, h->w, bwd, h->flag, st)); }
-        zin = zw;
-    }
-    // CISTA consumes the current voxel grid: in0 for eiflow, in1 (= image2) for eraft (e2v_model.py:194,246)
-    const float* ev_now = h->cfg.mode == CF_MODE_ERAFT ? in1 : in0;
-    rc = cista_forward(h, ev_now, h->warpedI, c_prev, zin, h_prev, cc_prev, I_out, c_out, z_out, h_out, cc_out, st);
-    h->phase_mark(3, st);
+    const StepArgs a = {in0, in1, rec_img0, flow_init, gt_flow, c_prev, z_prev, h_prev, cc_prev,
+                        I_out, flow_final, flow_low, flow_preds, z_warped_out, c_out, z_out, h_out, cc_out};
+    const bool reuse = eraft_begin(h);
+    const int rc = step_dispatch(h, a, reuse, st);
+    if (rc == CF_OK) eraft_done(h);
     h->ph_pending = h->phases && rc == CF_OK;
     return rc;
 }

@@ -138,6 +138,10 @@ hipError_t launch_pack_weight(const float* src, float* dst, int Cout, int Cin, i
 hipError_t launch_warp(const float* img, int img_ld, long img_bs, const float* flow, int Hf, int Wf,
                        float* out, int out_ld, long out_bs, int B, int C, int H, int W,
                        int backward, const int* flag, hipStream_t s);
+// the image warp and the sparse-code warp of one frame (e2v_model.py:186-191) in ONE launch; img2 == nullptr: one tensor
+hipError_t launch_warp2(const float* img, int img_ld, long img_bs, float* out, int out_ld, long out_bs, int C, int H, int W,
+                        const float* img2, int img2_ld, long img2_bs, float* out2, int out2_ld, long out2_bs, int C2, int H2,
+                        int W2, const float* flow, int Hf, int Wf, int B, int backward, const int* flag, hipStream_t s);
 // flag = any(flow != 0)
 hipError_t launch_any_nonzero(const float* x, long n, int* flag, hipStream_t s);
 

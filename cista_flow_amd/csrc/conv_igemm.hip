@@ -1052,6 +1052,7 @@ void conv_dma_kernel(const ConvParams p) {
     static_assert(WAVES_M * WAVES_N * WK == 4, "4 waves per workgroup");
 #ifdef CF_STAMP
     const long long t_begin = __builtin_readcyclecounter();
+    const long long r_begin = (long long)__builtin_amdgcn_s_memrealtime();     // 100 MHz wall clock
     long long st_wait = 0, st_bar = 0, st_issue = 0;
 #endif
     constexpr int KS = KCW * WK;
@@ -1396,7 +1397,10 @@ void conv_dma_kernel(const ConvParams p) {
     if (p.stamp && lane == 0) {      // [wait, barrier, issue, prologue, stages, loop, tail, -] cycles of this wave
         long long* q = p.stamp + ((long)blockIdx.x * 4 + wave) * 8;
         q[0] = st_wait; q[1] = st_bar; q[2] = st_issue; q[3] = t_loop_begin - t_begin; q[4] = nck;
-        q[5] = t_loop_end - t_loop_begin; q[6] = __builtin_readcyclecounter() - t_loop_end; q[7] = 0;
+        q[5] = t_loop_end - t_loop_begin; q[6] = __builtin_readcyclecounter() - t_loop_end;
+        // shader clock held over this wave's life in MHz: (cycle counter delta) / (100 MHz wall-clock delta) * 100
+        const long long dr = (long long)__builtin_amdgcn_s_memrealtime() - r_begin;
+        q[7] = dr > 0 ? ((__builtin_readcyclecounter() - t_begin) * 100) / dr : 0;
     }
 #endif
 }

@@ -3,138 +3,211 @@
 // Everything here moves each byte once: flow warp (bilinear gather), instance-norm
 // statistics / apply, ConvLSTM cell, correlation pyramid + lookup, flow up-sampling and the
 // NCHW<->NHWC boundary shuffles.  NHWC tensors are addressed as  base + b*bs + pixel*ld + c.
+#include "cf_device.h"
 #include "cf_kernels.h"
+
+#include <cstring>
 
 namespace cf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------
-// grid_sample coordinate helpers -- restated from ATen's CPU grid sampler
-// (align_corners=True): unnormalize = (g + 1) * ((size-1)/2); reflection about
-// [0, size-1]:  extra = |x| - trunc(|x| / (2*span)) * 2*span ; min(extra, 2*span - extra).
+// a4: flow warp.  utils/flow_utils.py:153-190 (forward: x - u) / :83-120 (backward: x + u); tap geometry in
+// cf_device.h::warp_taps.  HBM-bound: 4*(2C+2) bytes per pixel (every source row is read ~once through L2: each is a
+// tap of ~4 neighbouring output pixels), so the kernel is built around bytes in flight and L2 locality:
+//   * vector path (C % 4 == 0, C/4 a power of two <= 64): a workgroup owns 64..256 consecutive pixels.  Phase 1: one
+//     thread per pixel resamples the flow, reflects / clips and leaves the four tap offsets + weights in LDS (done
+//     once per pixel instead of once per 16-byte channel quad).  Phase 2: C/4 adjacent lanes own a pixel row (one
+//     512-byte row per half-wave at C = 128), read the taps as LDS broadcasts and keep 16 16-byte gathers in flight
+//     per lane before blending -- no index arithmetic in the loop;
+//   * workgroup -> pixel-strip map is XCD-aware (consecutive block ids are dealt round-robin over the 8 XCDs; each XCD
+//     gets one contiguous band of strips): vertically adjacent output rows share source rows, and without this every
+//     XCD's L2 fetched them again (PMC, round 1: 2.3x the algorithmic read bytes);
+//   * scalar path for any other C (C = 1: the image warp), one thread per (pixel, channel);
+//   * two tensors (image at full resolution + sparse code at half resolution, e2v_model.py:186-191) go through ONE
+//     launch: blocks [0, nblk_a) serve descriptor a, the rest descriptor b.
+// flag (nullable): device int; *flag == 0 (`flow_final.any()` false) turns the warp into a copy.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float reflect_coord(float x, int size) {
-    if (size <= 1) return 0.f;
-    const float twice_span = (float)(size - 1) * 2.f;
-    const float a = fabsf(x);
-    const float flips = truncf(a / twice_span);
-    const float extra = a - flips * twice_span;
-    return fminf(extra, twice_span - extra);
+struct WarpDesc {
+    const float* img; int ld; long bs;
+    float* out; int out_ld; long out_bs;
+    int C, H, W;
+    int vec;       // 1: vector path
+    int nblk;      // workgroups serving this tensor
+};
+
+__device__ __forceinline__ int xcd_band(int bid, int n) {      // block id -> logical strip (contiguous per XCD)
+    const int q8 = n >> 3, r8 = n & 7, xcd = bid & 7;
+    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
 }
 
-// interpolate(..., mode='bilinear', align_corners=True) source index for output index d
-__device__ __forceinline__ void ac_true_src(int d, int in, int out, int& i0, int& i1, float& l0, float& l1) {
-    const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
-    const float src = scale * (float)d;
-    i0 = (int)src;
-    i1 = i0 + (i0 < in - 1 ? 1 : 0);
-    l1 = src - (float)i0;
-    l0 = 1.f - l1;
-}
+struct WarpSlot {            // 64 bytes per pixel in LDS
+    long o[4];               // element offsets of the four taps (image base included); o[0] < 0: pixel past the end
+    long oo;                 // element offset of the output row
+    float w[4];
+    int pad[2];
+};
 
-// flow value at (b, ch, y, x) of a (H,W) grid, resampled from planar [B][2][Hf][Wf]
-__device__ __forceinline__ float flow_at(const float* flow, int b, int ch, int y, int x, int H, int W, int Hf, int Wf) {
-    const float* f = flow + ((long)b * 2 + ch) * Hf * Wf;
-    if (Hf == H && Wf == W) return f[(long)y * Wf + x];
-    int y0, y1, x0, x1;
-    float ly0, ly1, lx0, lx1;
-    ac_true_src(y, Hf, H, y0, y1, ly0, ly1);
-    ac_true_src(x, Wf, W, x0, x1, lx0, lx1);
-    const float v00 = f[(long)y0 * Wf + x0], v01 = f[(long)y0 * Wf + x1];
-    const float v10 = f[(long)y1 * Wf + x0], v11 = f[(long)y1 * Wf + x1];
-    return ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
-}
-
-// ---------------------------------------------------------------------------
-// a4: flow warp.  utils/flow_utils.py:153-190 (forward: x - u) / :83-120 (backward: x + u);
-// grid = 2*(xs/W - 0.5) with W, not W-1, then grid_sample(bilinear, align_corners=True,
-// padding_mode='reflection').  One thread = one pixel x 4 channels (16-byte accesses).
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ img, int img_ld, long img_bs,
-                                                   const float* __restrict__ flow, int Hf, int Wf,
-                                                   float* __restrict__ out, int out_ld, long out_bs, int B, int C,
-                                                   int H, int W, int backward, const int* flag, int cq /*quads per px*/,
-                                                   int vec) {
-    const long total = (long)B * H * W * cq;
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= total) return;
-    const int qd = (int)(gid % cq);
-    const long pix = gid / cq;
-    const int x = (int)(pix % W);
-    const int y = (int)((pix / W) % H);
-    const int b = (int)(pix / ((long)W * H));
-    const int c0 = qd * 4;
-    const float* ib = img + (long)b * img_bs;
-    float* ob = out + (long)b * out_bs + ((long)y * W + x) * out_ld + c0;
-
-    const bool passthrough = flag && (*flag == 0);
-    if (passthrough) {
-        const float* src = ib + ((long)y * W + x) * img_ld + c0;
-        if (vec) {
-            *reinterpret_cast<f32x4*>(ob) = *reinterpret_cast<const f32x4*>(src);
-        } else {
-            for (int e = 0; e < 4 && c0 + e < C; ++e) ob[e] = src[e];
+__device__ __forceinline__ void warp_vec_path(const WarpDesc& d, const float* __restrict__ flow, int Hf, int Wf, int B,
+                                              int backward, bool pass, int bid, WarpSlot* slots) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lpp = d.C >> 2;                               // lanes per pixel (power of two)
+    const int lsh = __builtin_ctz(lpp);
+    const int ppi = 64 >> lsh;                              // pixels per wave pass
+    const int ppw = ppi * 32 < 256 ? ppi * 32 : 256;        // pixels per workgroup
+    const int iters = ppw / (4 * ppi);                      // passes per wave (8 for C >= 32)
+    const int HW = d.H * d.W;
+    const long total = (long)B * HW;
+    const long base = (long)xcd_band(bid, d.nblk) * ppw;
+    if (tid < ppw) {
+        const long gp = base + tid;
+        WarpSlot s;
+        s.o[0] = -1; s.o[1] = s.o[2] = s.o[3] = 0; s.oo = 0;
+        s.w[0] = s.w[1] = s.w[2] = s.w[3] = 0.f;
+        if (gp < total) {
+            const int b = (int)(gp / HW);
+            const int p = (int)(gp - (long)b * HW);
+            const int y = p / d.W, x = p - y * d.W;
+            const long ib = (long)b * d.bs;
+            s.oo = (long)b * d.out_bs + (long)p * d.out_ld;
+            if (pass) {
+                s.o[0] = ib + (long)p * d.ld;
+            } else {
+                const float* f = flow + (long)b * 2 * Hf * Wf;
+                const float u = flow_at(f, y, x, d.H, d.W, Hf, Wf);
+                const float v = flow_at(f + (long)Hf * Wf, y, x, d.H, d.W, Hf, Wf);
+                const WarpTaps t = warp_taps(u, v, x, y, d.H, d.W, backward);
+                s.o[0] = ib + (long)t.p00 * d.ld; s.o[1] = ib + (long)t.p01 * d.ld;
+                s.o[2] = ib + (long)t.p10 * d.ld; s.o[3] = ib + (long)t.p11 * d.ld;
+                s.w[0] = t.w00; s.w[1] = t.w01; s.w[2] = t.w10; s.w[3] = t.w11;
+            }
         }
+        slots[tid] = s;
+    }
+    __syncthreads();
+    const int q4 = (lane & (lpp - 1)) * 4;
+    const int sub = lane >> lsh;
+    constexpr int BATCH = 4;
+    for (int it0 = 0; it0 < iters; it0 += BATCH) {
+        f32x4 v[BATCH][4];
+        bool ok[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            const bool live = it0 + j < iters;
+            const WarpSlot& s = slots[live ? (wave * iters + it0 + j) * ppi + sub : 0];     // live: index < ppw <= 256
+            ok[j] = live && s.o[0] >= 0;
+            if (ok[j]) {
+                v[j][0] = *reinterpret_cast<const f32x4*>(d.img + s.o[0] + q4);
+                if (!pass) {
+                    v[j][1] = *reinterpret_cast<const f32x4*>(d.img + s.o[1] + q4);
+                    v[j][2] = *reinterpret_cast<const f32x4*>(d.img + s.o[2] + q4);
+                    v[j][3] = *reinterpret_cast<const f32x4*>(d.img + s.o[3] + q4);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < BATCH; ++j) {
+            if (!ok[j]) continue;
+            const WarpSlot& s = slots[(wave * iters + it0 + j) * ppi + sub];
+            f32x4 r = v[j][0];
+            if (!pass) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    r[e] = v[j][0][e] * s.w[0] + v[j][1][e] * s.w[1] + v[j][2][e] * s.w[2] + v[j][3][e] * s.w[3];
+            }
+            *reinterpret_cast<f32x4*>(d.out + s.oo + q4) = r;
+        }
+    }
+}
+
+__device__ __forceinline__ void warp_scalar_path(const WarpDesc& d, const float* __restrict__ flow, int Hf, int Wf, int B,
+                                                 int backward, bool pass, int bid) {
+    // blocks per image = ceil(HW*C / 256); one thread per (pixel, channel), channel fastest
+    const unsigned per = (unsigned)d.H * d.W * d.C;
+    const unsigned bpi = (per + 255u) / 256u;
+    const int b = (int)((unsigned)bid / bpi);
+    const unsigned idx = ((unsigned)bid - (unsigned)b * bpi) * 256u + threadIdx.x;
+    if (b >= B || idx >= per) return;
+    const int p = (int)(idx / (unsigned)d.C);
+    const int c = (int)(idx - (unsigned)p * d.C);
+    const float* ib = d.img + (long)b * d.bs + c;
+    float* o = d.out + (long)b * d.out_bs + (long)p * d.out_ld + c;
+    if (pass) {
+        *o = ib[(long)p * d.ld];
         return;
     }
-    const float u = flow_at(flow, b, 0, y, x, H, W, Hf, Wf);
-    const float v = flow_at(flow, b, 1, y, x, H, W, Hf, Wf);
-    float xs = backward ? ((float)x + u) : ((float)x - u);
-    float ys = backward ? ((float)y + v) : ((float)y - v);
-    xs = 2.f * (xs / (float)W - 0.5f);
-    ys = 2.f * (ys / (float)H - 0.5f);
-    float ix = (xs + 1.f) * ((float)(W - 1) / 2.f);
-    float iy = (ys + 1.f) * ((float)(H - 1) / 2.f);
-    ix = reflect_coord(ix, W);
-    iy = reflect_coord(iy, H);
-    // clip (ATen clips after reflecting)
-    ix = fminf(fmaxf(ix, 0.f), (float)(W - 1));
-    iy = fminf(fmaxf(iy, 0.f), (float)(H - 1));
-    const float fx = floorf(ix), fy = floorf(iy);
-    const int x0 = (int)fx, y0 = (int)fy;
-    const int x1 = x0 + 1, y1 = y0 + 1;
-    const float tx = ix - fx, ty = iy - fy;   // ATen: w = x - x_w ; e = 1 - w
-    const float wx0 = 1.f - tx, wy0 = 1.f - ty;
-    const float w00 = wy0 * wx0, w01 = wy0 * tx, w10 = ty * wx0, w11 = ty * tx;
-    const bool x1ok = x1 <= W - 1, y1ok = y1 <= H - 1;   // x0,y0 always in range after the clip
-    const float* p00 = ib + ((long)y0 * W + x0) * img_ld + c0;
-    const float* p01 = ib + ((long)y0 * W + (x1ok ? x1 : x0)) * img_ld + c0;
-    const float* p10 = ib + ((long)(y1ok ? y1 : y0) * W + x0) * img_ld + c0;
-    const float* p11 = ib + ((long)(y1ok ? y1 : y0) * W + (x1ok ? x1 : x0)) * img_ld + c0;
-    const float m01 = x1ok ? 1.f : 0.f, m10 = y1ok ? 1.f : 0.f, m11 = (x1ok && y1ok) ? 1.f : 0.f;
-    if (vec) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(p00);
-        const f32x4 bq = *reinterpret_cast<const f32x4*>(p01);
-        const f32x4 cqv = *reinterpret_cast<const f32x4*>(p10);
-        const f32x4 d = *reinterpret_cast<const f32x4*>(p11);
-        f32x4 r;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            r[e] = a[e] * w00 + (bq[e] * m01) * w01 + (cqv[e] * m10) * w10 + (d[e] * m11) * w11;
-        *reinterpret_cast<f32x4*>(ob) = r;
+    const int y = p / d.W, x = p - y * d.W;
+    const float* f = flow + (long)b * 2 * Hf * Wf;
+    const float u = flow_at(f, y, x, d.H, d.W, Hf, Wf);
+    const float v = flow_at(f + (long)Hf * Wf, y, x, d.H, d.W, Hf, Wf);
+    const WarpTaps t = warp_taps(u, v, x, y, d.H, d.W, backward);
+    *o = ib[(long)t.p00 * d.ld] * t.w00 + ib[(long)t.p01 * d.ld] * t.w01 + ib[(long)t.p10 * d.ld] * t.w10 +
+         ib[(long)t.p11 * d.ld] * t.w11;
+}
+
+__global__ __launch_bounds__(256) void warp_kernel(const WarpDesc a, const WarpDesc b2, const float* __restrict__ flow, int Hf,
+                                                   int Wf, int B, int backward, const int* flag) {
+    __shared__ WarpSlot slots[256];
+    const bool pass = flag && (*flag == 0);
+    const int bid = blockIdx.x;
+    if (bid < a.nblk) {
+        if (a.vec) warp_vec_path(a, flow, Hf, Wf, B, backward, pass, bid, slots);
+        else warp_scalar_path(a, flow, Hf, Wf, B, backward, pass, bid);
     } else {
-        for (int e = 0; e < 4 && c0 + e < C; ++e)
-            ob[e] = p00[e] * w00 + (p01[e] * m01) * w01 + (p10[e] * m10) * w10 + (p11[e] * m11) * w11;
+        if (b2.vec) warp_vec_path(b2, flow, Hf, Wf, B, backward, pass, bid - a.nblk, slots);
+        else warp_scalar_path(b2, flow, Hf, Wf, B, backward, pass, bid - a.nblk);
     }
+}
+
+static bool warp_desc(WarpDesc& d, const float* img, int img_ld, long img_bs, float* out, int out_ld, long out_bs, int B, int C,
+                      int H, int W) {
+    if (!img || !out || C <= 0 || H <= 0 || W <= 0 || img_ld < C || out_ld < C) return false;
+    d.img = img; d.ld = img_ld; d.bs = img_bs; d.out = out; d.out_ld = out_ld; d.out_bs = out_bs; d.C = C; d.H = H; d.W = W;
+    const int lpp = C / 4;
+    d.vec = ((C % 4) == 0 && lpp <= 64 && (lpp & (lpp - 1)) == 0 && (img_ld % 4) == 0 && (out_ld % 4) == 0 && (img_bs % 4) == 0 &&
+             (out_bs % 4) == 0 && (reinterpret_cast<uintptr_t>(img) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0)
+                ? 1 : 0;
+    const long total = (long)B * H * W;
+    if (d.vec) {
+        const int ppi = 64 / lpp;
+        const int ppw = ppi * 32 < 256 ? ppi * 32 : 256;
+        d.nblk = (int)((total + ppw - 1) / ppw);
+    } else {
+        const long per = (long)H * W * C;
+        if (per >= 0x7FFFFFFFL) return false;
+        d.nblk = (int)(((per + 255) / 256) * B);
+    }
+    return total * C < (1L << 40);
+}
+
+// one or two tensors warped by the same flow in one launch (img2 == nullptr: one)
+hipError_t launch_warp2(const float* img, int img_ld, long img_bs, float* out, int out_ld, long out_bs, int C, int H, int W,
+                        const float* img2, int img2_ld, long img2_bs, float* out2, int out2_ld, long out2_bs, int C2, int H2,
+                        int W2, const float* flow, int Hf, int Wf, int B, int backward, const int* flag, hipStream_t s) {
+    if (!flow || B <= 0 || Hf <= 0 || Wf <= 0) return hipErrorInvalidValue;
+    WarpDesc a, b;
+    memset(&a, 0, sizeof(a));
+    memset(&b, 0, sizeof(b));
+    if (!warp_desc(a, img, img_ld, img_bs, out, out_ld, out_bs, B, C, H, W)) return hipErrorInvalidValue;
+    if (img2 && !warp_desc(b, img2, img2_ld, img2_bs, out2, out2_ld, out2_bs, B, C2, H2, W2)) return hipErrorInvalidValue;
+    if (b.vec && !a.vec) {       // the XCD band map keys on blockIdx & 7: the vector tensor's blocks must start at 0
+        const WarpDesc t = a;
+        a = b;
+        b = t;
+    }
+    const long blocks = (long)a.nblk + b.nblk;
+    if (blocks <= 0 || blocks >= 0x7FFFFFFFL) return hipErrorInvalidValue;
+    note_launch("warp_kernel", dim3((unsigned)blocks), dim3(256));
+    hipLaunchKernelGGL(warp_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, b, flow, Hf, Wf, B, backward, flag);
+    return hipGetLastError();
 }
 
 hipError_t launch_warp(const float* img, int img_ld, long img_bs, const float* flow, int Hf, int Wf, float* out,
                        int out_ld, long out_bs, int B, int C, int H, int W, int backward, const int* flag,
                        hipStream_t s) {
-    if (!img || !flow || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0 || Hf <= 0 || Wf <= 0) return hipErrorInvalidValue;
-    if (img_ld < C || out_ld < C) return hipErrorInvalidValue;
-    const int cq = (C + 3) / 4;
-    const int vec = ((C % 4) == 0 && (img_ld % 4) == 0 && (out_ld % 4) == 0 && (img_bs % 4) == 0 && (out_bs % 4) == 0 &&
-                     (reinterpret_cast<uintptr_t>(img) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0)
-                        ? 1
-                        : 0;
-    const long total = (long)B * H * W * cq;
-    const long blocks = (total + 255) / 256;
-    note_launch("warp_kernel", dim3((unsigned)blocks), dim3(256));
-    hipLaunchKernelGGL(warp_kernel, dim3((unsigned)blocks), dim3(256), 0, s, img, img_ld, img_bs, flow, Hf, Wf, out,
-                       out_ld, out_bs, B, C, H, W, backward, flag, cq, vec);
-    return hipGetLastError();
+    return launch_warp2(img, img_ld, img_bs, out, out_ld, out_bs, C, H, W, nullptr, 0, 0, nullptr, 0, 0, 0, 0, 0, flow, Hf, Wf,
+                        B, backward, flag, s);
 }
 
 // flag |= any(x != 0)   (NaN != 0 is true, like torch.Tensor.any on floats)
@@ -790,35 +863,53 @@ hipError_t launch_nhwc_to_nchw(const float* src, int src_ld, float* dst, int B, 
 // so that the following reflect-padded 3x3 conv can read it through the LDS-DMA kernel.  Same tap / blend arithmetic
 // as the fused A_UPS2X read of the convolution kernel.
 // ---------------------------------------------------------------------------
+// One thread = one channel quad of a 2x2 block of OUTPUT pixels {2k+1, 2k+2} x {2j+1, 2j+2}: with scale 2 /
+// align_corners=False those four share the source pixels {k, k+1} x {j, j+1}, so 4 16-byte loads feed 4 16-byte
+// stores (the one-thread-per-output form read 16).  Block rows / columns k, j = -1 and the last one are the image
+// border: source indices are clamped for the loads while every output keeps the weights of its own row / column
+// (same expressions as before: results are unchanged).
 __global__ __launch_bounds__(256) void upsample2x_nhwc_kernel(const float* __restrict__ src, int s_ld, long s_bs, float* __restrict__ dst,
                                                               int d_ld, long d_bs, int B, int Hs, int Ws, int C) {
-    // grid: x = quads of one output row (Wo * C/4), y = output row, z = image -- no 64-bit divisions per thread
     const int cq = C >> 2;
-    const int Wo = 2 * Ws;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Wo * cq) return;
-    const int ox = i / cq;
-    const int c0 = (i - ox * cq) * 4;
-    const int oy = blockIdx.y;
+    if (i >= (Ws + 1) * cq) return;
+    const int jj = i / cq;
+    const int c0 = (i - jj * cq) * 4;
+    const int j = jj - 1, k = (int)blockIdx.y - 1;
     const int b = blockIdx.z;
-    float sy = ((float)oy + 0.5f) * 0.5f - 0.5f;
-    float sx = ((float)ox + 0.5f) * 0.5f - 0.5f;
-    sy = sy < 0.f ? 0.f : sy;
-    sx = sx < 0.f ? 0.f : sx;
-    const int y0 = (int)sy, x0 = (int)sx;
-    const int y1 = y0 + (y0 < Hs - 1 ? 1 : 0);
-    const int x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
-    const float ly1 = sy - (float)y0, lx1 = sx - (float)x0;
-    const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+    const int r0 = k < 0 ? 0 : k, r1 = k + 1 > Hs - 1 ? Hs - 1 : k + 1;
+    const int q0 = j < 0 ? 0 : j, q1 = j + 1 > Ws - 1 ? Ws - 1 : j + 1;
     const float* sb = src + (long)b * s_bs + c0;
-    const f32x4 v00 = *reinterpret_cast<const f32x4*>(sb + (long)(y0 * Ws + x0) * s_ld);
-    const f32x4 v01 = *reinterpret_cast<const f32x4*>(sb + (long)(y0 * Ws + x1) * s_ld);
-    const f32x4 v10 = *reinterpret_cast<const f32x4*>(sb + (long)(y1 * Ws + x0) * s_ld);
-    const f32x4 v11 = *reinterpret_cast<const f32x4*>(sb + (long)(y1 * Ws + x1) * s_ld);
-    f32x4 v;
+    const f32x4 v00 = *reinterpret_cast<const f32x4*>(sb + (long)(r0 * Ws + q0) * s_ld);
+    const f32x4 v01 = *reinterpret_cast<const f32x4*>(sb + (long)(r0 * Ws + q1) * s_ld);
+    const f32x4 v10 = *reinterpret_cast<const f32x4*>(sb + (long)(r1 * Ws + q0) * s_ld);
+    const f32x4 v11 = *reinterpret_cast<const f32x4*>(sb + (long)(r1 * Ws + q1) * s_ld);
+    const int Wo = 2 * Ws, Ho = 2 * Hs;
+    float* db = dst + (long)b * d_bs + c0;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = ly0 * (lx0 * v00[e] + lx1 * v01[e]) + ly1 * (lx0 * v10[e] + lx1 * v11[e]);
-    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst + (long)b * d_bs + (long)(oy * Wo + ox) * d_ld + c0));
+    for (int a = 0; a < 2; ++a) {
+        const int oy = 2 * k + 1 + a;
+        if (oy < 0 || oy >= Ho) continue;
+        float sy = ((float)oy + 0.5f) * 0.5f - 0.5f;
+        sy = sy < 0.f ? 0.f : sy;
+        const int y0 = (int)sy;
+        const float ly1 = sy - (float)y0, ly0 = 1.f - ly1;
+        // (y0, y1) of this output row is (r0, r1); on the clamped border rows both taps hold the same data or the
+        // far tap has weight 0
+#pragma unroll
+        for (int e2 = 0; e2 < 2; ++e2) {
+            const int ox = 2 * j + 1 + e2;
+            if (ox < 0 || ox >= Wo) continue;
+            float sx = ((float)ox + 0.5f) * 0.5f - 0.5f;
+            sx = sx < 0.f ? 0.f : sx;
+            const int x0 = (int)sx;
+            const float lx1 = sx - (float)x0, lx0 = 1.f - lx1;
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ly0 * (lx0 * v00[e] + lx1 * v01[e]) + ly1 * (lx0 * v10[e] + lx1 * v11[e]);
+            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(db + (long)(oy * Wo + ox) * d_ld));
+        }
+    }
 }
 
 hipError_t launch_upsample2x_nhwc(const float* src, int s_ld, long s_bs, float* dst, int d_ld, long d_bs, int B, int Hs, int Ws,
@@ -826,10 +917,10 @@ hipError_t launch_upsample2x_nhwc(const float* src, int s_ld, long s_bs, float* 
     if (!src || !dst || B <= 0 || Hs <= 0 || Ws <= 0 || C <= 0 || (C % 4) != 0 || (s_ld % 4) != 0 || (d_ld % 4) != 0 ||
         (s_bs % 4) != 0 || (d_bs % 4) != 0 || (reinterpret_cast<uintptr_t>(src) & 15) != 0 || (reinterpret_cast<uintptr_t>(dst) & 15) != 0)
         return hipErrorInvalidValue;
-    if (2 * Hs > 65535 || B > 65535) return hipErrorInvalidValue;
-    const int row = 2 * Ws * (C / 4);
-    note_launch("upsample2x_nhwc_kernel", dim3((unsigned)((row + 255) / 256), 2 * Hs, B), dim3(256));
-    hipLaunchKernelGGL(upsample2x_nhwc_kernel, dim3((unsigned)((row + 255) / 256), 2 * Hs, B), dim3(256), 0, s, src, s_ld, s_bs, dst, d_ld,
+    if (Hs + 1 > 65535 || B > 65535) return hipErrorInvalidValue;
+    const int row = (Ws + 1) * (C / 4);
+    note_launch("upsample2x_nhwc_kernel", dim3((unsigned)((row + 255) / 256), Hs + 1, B), dim3(256));
+    hipLaunchKernelGGL(upsample2x_nhwc_kernel, dim3((unsigned)((row + 255) / 256), Hs + 1, B), dim3(256), 0, s, src, s_ld, s_bs, dst, d_ld,
                        d_bs, B, Hs, Ws, C);
     return hipGetLastError();
 }

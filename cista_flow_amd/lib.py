@@ -21,6 +21,7 @@ SYMBOLS = [
     "cf_op_conv2d", "cf_op_instance_norm_relu", "cf_op_corr_lookup", "cf_op_nchw_to_nhwc",
     "cf_op_nhwc_to_nchw", "cf_profile_enable", "cf_profile_read", "cf_conv_tile_name", "cf_profile_report", "cf_op_conv2d_bench", "cf_events_to_voxel", "cf_op_conv2d_inorm_stats", "cf_quantize_u8", "cf_hint_prev_grid",
     "cf_profile_report_json", "cf_metrics_scratch_doubles", "cf_metrics_recon", "cf_metrics_flow", "cf_metrics_fwl",
+    "cf_graph_enable", "cf_graph_stats",
 ]
 
 
@@ -96,6 +97,10 @@ def load():
     lib.cf_metrics_flow.restype = i
     lib.cf_metrics_fwl.argtypes = [fp, fp, i, i, i, i, fp, fp, vp]
     lib.cf_metrics_fwl.restype = i
+    lib.cf_graph_enable.argtypes = [vp, i]
+    lib.cf_graph_enable.restype = i
+    lib.cf_graph_stats.argtypes = [vp, C.POINTER(C.c_longlong)]
+    lib.cf_graph_stats.restype = i
     lib.cf_hint_prev_grid.argtypes = [vp, i]
     lib.cf_hint_prev_grid.restype = i
     lib.cf_profile_enable.argtypes = [vp, i]
@@ -171,6 +176,16 @@ class Handle:
             self.check(self.lib.cf_load_weights(self.h, k.encode(), ptr(t), shp, t.dim()), "cf_load_weights(%s)" % k)
         self.check(self.lib.cf_finalize_weights(self.h, current_stream_ptr(self.cfg.device)), "cf_finalize_weights")
         del keep
+
+    def graph_enable(self, on=True):
+        """hipGraph replay of cf_step (default on unless CF_GRAPH=0)."""
+        self.check(self.lib.cf_graph_enable(self.h, 1 if on else 0), "cf_graph_enable")
+
+    def graph_stats(self):
+        """-> (captures, replays, executables cached)."""
+        out = (C.c_longlong * 3)()
+        self.check(self.lib.cf_graph_stats(self.h, out), "cf_graph_stats")
+        return int(out[0]), int(out[1]), int(out[2])
 
     def profile_enable(self, on=True):
         self.check(self.lib.cf_profile_enable(self.h, 1 if on else 0), "cf_profile_enable")

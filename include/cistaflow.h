@@ -111,6 +111,15 @@ int cf_step(cf_handle* h, const float* in0, const float* in1, const float* rec_i
             const float* cc_prev, float* I_out, float* flow_final, float* flow_low, float* flow_preds,
             float* z_warped_out, float* c_out, float* z_out, float* h_out, float* cc_out, void* stream);
 
+/* hipGraph replay of cf_step (on by default; environment CF_GRAPH=0 turns it off).  A step is several hundred launches
+ * over up to four streams; the library captures it once per distinct tuple of the 18 caller pointers (the second time
+ * a tuple is seen) and replays the executable on a hit -- the same kernels with the same arguments, so results are
+ * bit-identical to the eager path; callers whose buffers never repeat stay on the eager path.  Bypassed while
+ * cf_profile_enable / CF_PHASES / CF_SERIAL are active and when `stream` is itself being captured.
+ * cf_graph_stats: out3 = {captures, replays, executables cached}. */
+int cf_graph_enable(cf_handle* h, int on);
+int cf_graph_stats(const cf_handle* h, long long* out3);
+
 /* f-1 (next row): events_to_voxel_grid + event_preprocess('std') (utils/event_process.py:15-72,193-216).
  * events: device [total][4] fp64 rows (timestamp, x, y, polarity), the B sequences' events concatenated in time
  * order; offsets: device int64 [B+1]; voxel: [B][bins][H][W] fp32; stats_scratch: 3*B doubles. */

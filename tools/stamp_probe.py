@@ -19,7 +19,7 @@ buf = torch.zeros(8 * 4 * 40000, dtype=torch.int64, device="cuda")
 os.environ["CF_STAMP_BUF"] = str(buf.data_ptr())
 import conv_bench  # noqa: E402
 
-CASES = os.environ.get("CASES", "cista.D:26,cista.D:23,cista.P:23,gates:26,gru.zr:20,gru.q:22,layer1:26")
+CASES = os.environ.get("CASES", "cista.D:23,cista.P:23,cista.P:28,gates:28,gates:25,gru.zr:20,gru.q:22,convc2:20,layer1:23")
 for case in CASES.split(","):
     name, tile = case.split(":")
     shape = [s for s in conv_bench.SHAPES if s[0].startswith(name)][0]
@@ -32,5 +32,5 @@ for case in CASES.split(","):
     m = d.mean(0)
     comp = (m[5] - m[0] - m[1] - m[2]) / n
     print("%-34s tile %2d  %7.1f us %5.1f TF | stages %3d | per stage: vmcnt-wait %4.0f  barrier %4.0f  issue %4.0f  lds+mfma %4.0f"
-          " | prologue %6.0f  loop %7.0f  tail %6.0f cycles" % (shape[0], int(tile), r[0], r[1], n, m[0] / n, m[1] / n, m[2] / n,
-                                                              comp, m[3], m[5], m[6]), flush=True)
+          " | prologue %6.0f  loop %7.0f  tail %6.0f cycles | shader clock %4.0f MHz (median %4.0f)" % (
+              shape[0], int(tile), r[0], r[1], n, m[0] / n, m[1] / n, m[2] / n, comp, m[3], m[5], m[6], m[7], d[:, 7].median().item()), flush=True)
