@@ -43,6 +43,8 @@ struct PackedConv {
     void* w16 = nullptr;     // f16 hi/lo split copy (precision != 0)
     float* bias = nullptr;
     int cout = 0, cin = 0, cin_pad = 0, KH = 0, KW = 0, Ktot = 0, rows = 0;
+    int groups = 1;          // > 1: `groups` matrices [rows][Ktot] (+ biases [rows]) back to back: the same layer of
+                             // several networks, run as one launch over a groups*B batch (ConvParams::w_div)
     bool gather = false;
     std::string name;
 };
@@ -97,7 +99,7 @@ struct cf_handle {
     hipStream_t aux[3] = {nullptr, nullptr, nullptr};   // library-owned side streams
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_upf = nullptr, ev_up = nullptr;   // intermediate up-sampling on side stream 1 (fork / done)
-    float *fmap1 = nullptr, *emap = nullptr, *fcat = nullptr, *pfmap2 = nullptr, *net = nullptr, *inp = nullptr;
+    float *fpair = nullptr, *fmap1 = nullptr, *emap = nullptr, *fcat = nullptr, *pfmap2 = nullptr, *net = nullptr, *inp = nullptr;
     // ERAFT: the driver's in0 of step t is its in1 of step t-1 (test_with_flow.py:144-149), so fnet(in0) is the feature
     // map the previous step left in pfmap2.  cf_hint_prev_grid() arms the reuse for the next cf_step / cf_flow_forward.
     bool fmap2_valid = false, reuse_next = false;
@@ -123,6 +125,7 @@ struct cf_handle {
     bool serial_env = false;
     // batch window applied by run_conv (images [win_b0, win_b0 + win_n) of every tensor); win_n == 0: whole batch
     int win_b0 = 0, win_n = 0;
+    int enc_tile_batch = 0;        // tile-choice batch of the encoder being issued (ConvParams::tile_batch)
     // CF_PHASES=1 (tuning aid): HIP events on the caller's stream at the phase boundaries of cf_step, averaged
     // and printed to stderr by cf_destroy
     bool phases = false;
@@ -168,6 +171,7 @@ struct cf_handle {
     std::vector<GraphEntry> graphs;
     std::vector<GraphKey> seen;
     bool graph_on = false;
+    bool graph_serial = false;     // CF_GRAPH_SERIAL=1 (experiment): capture the step as ONE chain (no side streams)
     unsigned long graph_tick = 0;
     long long graph_captures = 0, graph_replays = 0;
     hipStream_t gstream = nullptr;               // stands in for the (uncapturable) legacy stream
@@ -229,6 +233,11 @@ static hipError_t run_conv(cf_handle* h, const ConvParams& p_in, int batch, hipS
         if (p.aux2) p.aux2 += b0 * p.aux2_bs;
         if (p.aux3) p.aux3 += b0 * p.aux3_bs;
         if (p.addend) p.addend += b0 * p.addend_bs;
+    }
+    if (h && h->enc_tile_batch > 0) p.tile_batch = h->enc_tile_batch;
+    if (p.w_div < 0) {
+        if (batch % (-p.w_div) != 0) return hipErrorInvalidValue;
+        p.w_div = batch / (-p.w_div);
     }
     if (!h || !h->prof) return launch_conv(p, batch, st, tile);
     cf_handle::ProfRec r;
@@ -332,19 +341,28 @@ static void setup_buffers(cf_handle* H_) {
     s.zwarp = a.f(B * hw * 2 * bc);
     if (s.cfg.mode == CF_MODE_EIFLOW || s.cfg.mode == CF_MODE_ERAFT) {
         const size_t P1 = (size_t)s.H1 * s.W1, N = s.N;
-        for (int e = 0; e < 3; ++e) {
-            s.enc[e].A = a.f(B * P1 * 64);
-            s.enc[e].B = a.f(B * P1 * 64);
-            s.enc[e].C = a.f(B * P1 * 64);
-            s.enc[e].D = a.f(B * P1 * 64);
-            s.enc[e].stats = a.f(B * 256 * 2);
-            s.enc[e].stats2 = a.f(B * 256 * 2);
-            s.enc[e].partial = reinterpret_cast<double*>(a.raw(sizeof(double) * (size_t)inorm_patch_doubles(s.B, (int)P1, 128)));
+        // scratch set 0: the batched encoder pair (2B images); set 2: cnet (B images); set 1 unused
+        for (int e = 0; e < 3; e += 2) {
+            const size_t nb = e == 0 ? 2 * B : B;
+            s.enc[e].A = a.f(nb * P1 * 64);
+            s.enc[e].B = a.f(nb * P1 * 64);
+            s.enc[e].C = a.f(nb * P1 * 64);
+            s.enc[e].D = a.f(nb * P1 * 64);
+            s.enc[e].stats = a.f(nb * 256 * 2);
+            s.enc[e].stats2 = a.f(nb * 256 * 2);
+            s.enc[e].partial = reinterpret_cast<double*>(a.raw(sizeof(double) * (size_t)inorm_patch_doubles((int)nb, (int)P1, 128)));
         }
-        s.fmap1 = a.f(B * N * 256);
-        s.emap = a.f(B * N * 256);
+        // the pair's output [2B][N][256]: fmap1 | emap (eiflow), fnet(old grid) | fnet(new grid) (eraft)
+        s.fpair = a.f(2 * B * N * 256);
+        s.fmap1 = s.fpair;
         s.fcat = a.f(B * N * 384);
-        s.pfmap2 = a.f(B * N * 256);
+        if (s.cfg.mode == CF_MODE_EIFLOW) {
+            s.emap = s.fpair + B * N * 256;
+            s.pfmap2 = a.f(B * N * 256);
+        } else {
+            s.emap = nullptr;
+            s.pfmap2 = s.fpair + B * N * 256;
+        }
         s.net = a.f(B * N * 128);
         s.inp = a.f(B * N * 128);
         int lh = s.h8, lw = s.w8;
@@ -431,6 +449,11 @@ ConvParams nhwc_conv(const PackedConv& pc, std::initializer_list<Seg> segs, int 
     p.KH = pc.KH; p.KW = pc.KW; p.stride = stride; p.padT = padT; p.padL = padL; p.pad_mode = pad_mode;
     p.a_mode = A_NHWC;
     p.w = pc.w; p.w16 = pc.w16; p.w_bs = 0; p.w_rows = pc.rows; p.Ktot = pc.Ktot; p.cin_pad = pc.cin_pad; p.bias = pc.bias;
+    if (pc.groups > 1) {     // images [g*batch/groups, (g+1)*batch/groups) use matrix g; run_conv turns w_div into images per group
+        p.w_bs = (long)pc.rows * pc.Ktot;
+        p.bias_gs = pc.rows;
+        p.w_div = -pc.groups;
+    }
     p.out = out; p.out_ld = out_ld; p.out_bs = out_bs; p.cout = pc.cout; p.epi = epi;
     p.k_real = pc.cin * pc.KH * pc.KW;
     p.tag = pc.name.c_str();
@@ -478,7 +501,7 @@ struct CinSlice { int begin, count, dst; int accum = 0; };
 static int pack_conv(cf_handle* h, const std::string& key, const std::string& prefix, bool gather, int row0,
                      int total_rows, const std::string& bn_prefix, hipStream_t st,
                      const std::vector<CinSlice>& slices = {}, int packed_cin = 0, bool with_bias = true,
-                     int interleave = 0) {
+                     int interleave = 0, int group = 0, int groups = 1) {
     const RawWeight* wt = find_raw(h, prefix + ".weight");
     const RawWeight* bs = find_raw(h, prefix + ".bias");
     if (!wt || wt->shape.size() != 4) return h->fail(CF_ERR_WEIGHT, "missing or non-4D weight: " + prefix + ".weight");
@@ -499,17 +522,21 @@ static int pack_conv(cf_handle* h, const std::string& key, const std::string& pr
                                                    " exceeds the 256-column limit of the planar gather convolution (num_bins too large for this kernel size)");
         pc.cout = total_rows > 0 ? total_rows : Cout;
         pc.rows = round_up(pc.cout, 128);
-        const size_t wbytes = (size_t)pc.rows * pc.Ktot * sizeof(float);
+        pc.groups = groups;
+        const size_t wbytes = (size_t)pc.rows * pc.Ktot * sizeof(float) * groups;
         CF_HIP(h, hipMalloc(reinterpret_cast<void**>(&pc.w), wbytes));
         h->owned.push_back(pc.w);
-        CF_HIP(h, hipMalloc(reinterpret_cast<void**>(&pc.bias), pc.rows * sizeof(float)));
+        CF_HIP(h, hipMalloc(reinterpret_cast<void**>(&pc.bias), pc.rows * sizeof(float) * groups));
         h->owned.push_back(pc.bias);
         CF_HIP(h, hipMemsetAsync(pc.w, 0, wbytes, st));
-        CF_HIP(h, hipMemsetAsync(pc.bias, 0, pc.rows * sizeof(float), st));
+        CF_HIP(h, hipMemsetAsync(pc.bias, 0, pc.rows * sizeof(float) * groups, st));
     } else {
-        if (pc.cin != cin_eff || pc.KH != KH || pc.KW != KW) return h->fail(CF_ERR_WEIGHT, "stacked conv shape mismatch: " + prefix);
+        if (pc.cin != cin_eff || pc.KH != KH || pc.KW != KW || pc.groups != groups)
+            return h->fail(CF_ERR_WEIGHT, "stacked conv shape mismatch: " + prefix);
     }
-    if (row0 + Cout > pc.rows) return h->fail(CF_ERR_WEIGHT, "stacked conv overflows: " + prefix);
+    if (row0 + Cout > pc.rows || group < 0 || group >= pc.groups) return h->fail(CF_ERR_WEIGHT, "stacked conv overflows: " + prefix);
+    float* const gw = pc.w + (size_t)group * pc.rows * pc.Ktot;      // this group's matrix / bias
+    float* const gb = pc.bias + (size_t)group * pc.rows;
     const float *bw = nullptr, *bb = nullptr, *bm = nullptr, *bv = nullptr;
     if (!bn_prefix.empty()) {
         const RawWeight* r0 = find_raw(h, bn_prefix + ".weight");
@@ -523,22 +550,29 @@ static int pack_conv(cf_handle* h, const std::string& key, const std::string& pr
     }
     const float* bsrc = (bs && with_bias) ? bs->ptr : nullptr;
     if (slices.empty()) {
-        CF_HIP(h, launch_pack_weight(wt->ptr, pc.w, Cout, Cin, KH, KW, pc.cin_pad, pc.Ktot, row0, gather ? 1 : 0, 0, 0, 0, 0, bw,
-                                     bb, bm, bv, 1e-5f, bsrc, pc.bias, st, interleave));
+        CF_HIP(h, launch_pack_weight(wt->ptr, gw, Cout, Cin, KH, KW, pc.cin_pad, pc.Ktot, row0, gather ? 1 : 0, 0, 0, 0, 0, bw,
+                                     bb, bm, bv, 1e-5f, bsrc, gb, st, interleave));
     } else {
         for (const CinSlice& sl : slices)
-            CF_HIP(h, launch_pack_weight(wt->ptr, pc.w, Cout, Cin, KH, KW, pc.cin_pad, pc.Ktot, row0, gather ? 1 : 0, sl.begin,
-                                         sl.count, sl.dst, sl.accum, bw, bb, bm, bv, 1e-5f, bsrc, pc.bias, st));
+            CF_HIP(h, launch_pack_weight(wt->ptr, gw, Cout, Cin, KH, KW, pc.cin_pad, pc.Ktot, row0, gather ? 1 : 0, sl.begin,
+                                         sl.count, sl.dst, sl.accum, bw, bb, bm, bv, 1e-5f, bsrc, gb, st));
     }
     return CF_OK;
 }
 
-static int pack_encoder(cf_handle* h, const std::string& pre, const std::string& keypre, bool bn, hipStream_t st) {
+// group / groups: the 3x3 / 1x1 layers of several encoders with identical shapes share one PackedConv (groups matrices back
+// to back) so that they run as single launches over a groups*B batch; conv1 (different Cin per network) stays per network
+// under `conv1_keypre`
+static int pack_encoder(cf_handle* h, const std::string& pre, const std::string& keypre, bool bn, hipStream_t st, int group = 0,
+                        int groups = 1, const std::string& conv1_keypre = std::string()) {
     int rc;
     auto P = [&](const std::string& key, const std::string& name, bool gather, const std::string& bnname) -> int {
-        return pack_conv(h, keypre + "." + key, pre + "." + name, gather, 0, 0, bn ? pre + "." + bnname : std::string(), st);
+        return pack_conv(h, keypre + "." + key, pre + "." + name, gather, 0, 0, bn ? pre + "." + bnname : std::string(), st, {}, 0, true, 0,
+                         group, groups);
     };
-    if ((rc = P("conv1", "conv1", true, "norm1"))) return rc;
+    if ((rc = pack_conv(h, (conv1_keypre.empty() ? keypre : conv1_keypre) + ".conv1", pre + ".conv1", true, 0, 0,
+                        bn ? pre + ".norm1" : std::string(), st)))
+        return rc;
     for (int L = 1; L <= 3; ++L) {
         for (int blk = 0; blk < 2; ++blk) {
             const std::string b = "layer" + std::to_string(L) + "." + std::to_string(blk);
@@ -548,7 +582,7 @@ static int pack_encoder(cf_handle* h, const std::string& pre, const std::string&
                 if ((rc = P(b + ".downsample.0", b + ".downsample.0", false, b + ".downsample.1"))) return rc;
         }
     }
-    return pack_conv(h, keypre + ".conv2", pre + ".conv2", false, 0, 0, "", st);
+    return pack_conv(h, keypre + ".conv2", pre + ".conv2", false, 0, 0, "", st, {}, 0, true, 0, group, groups);
 }
 
 extern "C" int cf_load_weights(cf_handle* h, const char* name, const void* dev_ptr, const int64_t* shape, int ndim) {
@@ -616,8 +650,13 @@ extern "C" int cf_finalize_weights(cf_handle* h, void* stream) {
     const bool eraft = h->cfg.mode == CF_MODE_ERAFT;
     if (got_flow && (h->cfg.mode == CF_MODE_EIFLOW || eraft)) {
         const std::string& f = fn;
-        if ((rc = pack_encoder(h, f + "fnet", "event_flownet.fnet", false, st))) return rc;
-        if (!eraft && (rc = pack_encoder(h, f + "enet", "event_flownet.enet", false, st))) return rc;
+        if (eraft) {
+            if ((rc = pack_encoder(h, f + "fnet", "event_flownet.fnet", false, st))) return rc;
+        } else {
+            // fnet and enet have identical layer shapes after conv1: packed as matrix 0 / 1 of one grouped PackedConv per layer
+            if ((rc = pack_encoder(h, f + "fnet", "event_flownet.pair", false, st, 0, 2, "event_flownet.fnet"))) return rc;
+            if ((rc = pack_encoder(h, f + "enet", "event_flownet.pair", false, st, 1, 2, "event_flownet.enet"))) return rc;
+        }
         if ((rc = pack_encoder(h, f + "cnet", "event_flownet.cnet", true, st))) return rc;
         auto F = [&](const std::string& key, const std::string& name, bool gather) -> int {
             return pack_conv(h, key, f + name, gather, 0, 0, "", st);
@@ -712,9 +751,9 @@ extern "C" int cf_finalize_weights(cf_handle* h, void* stream) {
         for (auto& kv : h->conv) {
             PackedConv& pc = kv.second;
             if (!pc.w) continue;
-            CF_HIP(h, hipMalloc(&pc.w16, (size_t)pc.rows * pc.Ktot * sizeof(float)));
+            CF_HIP(h, hipMalloc(&pc.w16, (size_t)pc.rows * pc.groups * pc.Ktot * sizeof(float)));
             h->owned.push_back(pc.w16);
-            CF_HIP(h, launch_split_weight_f16(pc.w, pc.w16, pc.rows, pc.Ktot, st));
+            CF_HIP(h, launch_split_weight_f16(pc.w, pc.w16, (long)pc.rows * pc.groups, pc.Ktot, st));
         }
     }
     // the announced pointers may die after this call: drain the packing kernels
@@ -804,6 +843,10 @@ extern "C" int cf_create(cf_handle** out, const cf_config* cfg) {
     // CF_GRAPH=0|1 overrides the default (host time per step)
     h->graph_on = true;
     if (const char* e = getenv("CF_GRAPH")) h->graph_on = atoi(e) != 0;
+    if (const char* e = getenv("CF_GRAPH_SERIAL")) {
+        h->graph_serial = atoi(e) != 0;
+        if (h->graph_serial) h->serial = h->serial_env = true;
+    }
     if (!ok) {
         (void)hipFree(h->arena_mem);
         delete h;
@@ -1098,26 +1141,42 @@ extern "C" int cf_cista_forward(cf_handle* h, const float* ev, const float* img,
 // ---------------------------------------------------------------------------------------------
 // BasicEncoder  raft_encoder.py:179-203
 // ---------------------------------------------------------------------------------------------
-// in: planar [B][Cin][H][W] (un-padded); out: NHWC [B][N][256] (or tanh|relu split when out2 != null)
-static int encoder_forward(cf_handle* h, const std::string& pre, bool bn, const float* in, int Cin, float scale,
-                           float shift, float* out, float* out2, int scratch, hipStream_t st) {
-    const int B = h->B;
+// One encoder, or `nin` encoders of identical layer shapes as ONE batch of nin*B images (instance norm is per sample, so
+// batching changes nothing): input g is planar [B][Cin_g][H][W] (un-padded) and goes through its own conv1
+// (`conv1_key`); the remaining layers are single launches over the whole batch with the (grouped) weights under `pre`.
+// out: NHWC [nin*B][N][256] (or, nin == 1 only, the tanh | relu split of cnet when out2 != null).
+struct EncIn {
+    const float* in;
+    int Cin;
+    float scale, shift;
+    std::string conv1_key;
+};
+
+static int encoder_forward(cf_handle* h, const std::string& pre, bool bn, const EncIn* ins, int nin, float* out, float* out2,
+                           int scratch, hipStream_t st, int tile_batch = 0) {
+    const int B = h->B, BB = nin * h->B;
+    h->enc_tile_batch = tile_batch;
+    struct Reset { cf_handle* h; ~Reset() { h->enc_tile_batch = 0; } } reset_{h};
     const float eps = 1e-5f;
     int Hc = h->H1, Wc = h->W1;   // current resolution
     cf_handle::EncScratch& sc = h->enc[scratch];
     float *A = sc.A, *Bf = sc.B, *Cf = sc.C, *Df = sc.D;
     auto K = [&](const std::string& k) -> const PackedConv& { return h->conv[pre + "." + k]; };
-    // conv1 7x7 s2 (+norm1 + relu)
+    // conv1 7x7 s2 (+norm1 + relu), one launch per input
     {
-        ConvParams p = gather_conv(K("conv1"), in, Cin, h->H, h->W, h->padH, h->padW, scale, shift, 0, Hc, Wc, 2, 3, 3, 0,
-                                   bn ? A : Bf, 64, (long)Hc * Wc * 64, bn ? EPI_RELU : EPI_NONE);
-        if (!bn) p.st_partial = sc.partial;      // InstanceNorm statistics ride on the conv epilogue
-        CF_HIP(h, run_conv(h, p, B, st));
+        const long obs = (long)Hc * Wc * 64;
+        const long npatch = (Hc * Wc + 31) / 32;
+        for (int g = 0; g < nin; ++g) {
+            ConvParams p = gather_conv(h->conv[ins[g].conv1_key + ".conv1"], ins[g].in, ins[g].Cin, h->H, h->W, h->padH, h->padW,
+                                       ins[g].scale, ins[g].shift, 0, Hc, Wc, 2, 3, 3, 0, (bn ? A : Bf) + (long)g * B * obs, 64, obs,
+                                       bn ? EPI_RELU : EPI_NONE);
+            if (!bn) p.st_partial = sc.partial + (long)g * B * npatch * 64 * 2;      // InstanceNorm statistics ride on the conv epilogue
+            CF_HIP(h, run_conv(h, p, B, st));
+        }
         if (!bn) {
-            { PROF(h, st, "enc.inorm_final", 16.0 * B * ((Hc * Wc + 31) / 32) * 64); CF_HIP(h, launch_inorm_final(sc.partial, (Hc * Wc + 31) / 32, B, Hc * Wc, 64, eps, sc.stats, st)); }
-            { PROF(h, st, "enc.inorm_apply", 8.0 * B * Hc * Wc * 64);
-              CF_HIP(h, launch_inorm_apply(Bf, 64, (long)Hc * Wc * 64, sc.stats, nullptr, 0, 0, nullptr, A, 64,
-                                           (long)Hc * Wc * 64, B, Hc * Wc, 64, st)); }
+            { PROF(h, st, "enc.inorm_final", 16.0 * BB * npatch * 64); CF_HIP(h, launch_inorm_final(sc.partial, (int)npatch, BB, Hc * Wc, 64, eps, sc.stats, st)); }
+            { PROF(h, st, "enc.inorm_apply", 8.0 * BB * Hc * Wc * 64);
+              CF_HIP(h, launch_inorm_apply(Bf, 64, obs, sc.stats, nullptr, 0, 0, nullptr, A, 64, obs, BB, Hc * Wc, 64, st)); }
         }
     }
     // x lives in A; scratch Bf, Cf, Df
@@ -1133,29 +1192,30 @@ static int encoder_forward(cf_handle* h, const std::string& pre, bool bn, const 
             if (bn) {
                 // y = relu(bn1(conv1(x))) ; y = relu(bn2(conv2(y))) ; out = relu(x' + y)
                 ConvParams c1 = nhwc_conv(K(b + ".conv1"), {{A, Cx, Cx, ibs}}, Hc, Wc, Ho, Wo, stride, 1, 1, 0, Bf, Cd, obs, EPI_RELU);
-                CF_HIP(h, run_conv(h, c1, B, st));
+                CF_HIP(h, run_conv(h, c1, BB, st));
                 const float* res = A;
                 int res_ld = Cx;
                 long res_bs = ibs;
                 if (stride != 1) {
                     ConvParams ds = nhwc_conv(K(b + ".downsample.0"), {{A, Cx, Cx, ibs}}, Hc, Wc, Ho, Wo, stride, 0, 0, 0, Cf, Cd, obs, EPI_NONE);
-                    CF_HIP(h, run_conv(h, ds, B, st));
+                    CF_HIP(h, run_conv(h, ds, BB, st));
                     res = Cf; res_ld = Cd; res_bs = obs;
                 }
                 ConvParams c2 = nhwc_conv(K(b + ".conv2"), {{Bf, Cd, Cd, obs}}, Ho, Wo, Ho, Wo, 1, 1, 1, 0, Df, Cd, obs, EPI_RELU_ADD_AUX_RELU);
                 set_aux0(c2, res, res_ld, res_bs);
-                CF_HIP(h, run_conv(h, c2, B, st));
+                CF_HIP(h, run_conv(h, c2, BB, st));
                 std::swap(A, Df);
             } else {
+                const int nch = (Ho * Wo + 31) / 32;
                 ConvParams c1 = nhwc_conv(K(b + ".conv1"), {{A, Cx, Cx, ibs}}, Hc, Wc, Ho, Wo, stride, 1, 1, 0, Bf, Cd, obs, EPI_NONE);
                 c1.st_partial = sc.partial;
-                CF_HIP(h, run_conv(h, c1, B, st));
-                { PROF(h, st, "enc.inorm_final", 16.0 * B * ((Ho * Wo + 31) / 32) * Cd); CF_HIP(h, launch_inorm_final(sc.partial, (Ho * Wo + 31) / 32, B, Ho * Wo, Cd, eps, sc.stats, st)); }
-                { PROF(h, st, "enc.inorm_apply", 8.0 * B * Ho * Wo * Cd); CF_HIP(h, launch_inorm_apply(Bf, Cd, obs, sc.stats, nullptr, 0, 0, nullptr, Cf, Cd, obs, B, Ho * Wo, Cd, st)); }
+                CF_HIP(h, run_conv(h, c1, BB, st));
+                { PROF(h, st, "enc.inorm_final", 16.0 * BB * nch * Cd); CF_HIP(h, launch_inorm_final(sc.partial, nch, BB, Ho * Wo, Cd, eps, sc.stats, st)); }
+                { PROF(h, st, "enc.inorm_apply", 8.0 * BB * Ho * Wo * Cd); CF_HIP(h, launch_inorm_apply(Bf, Cd, obs, sc.stats, nullptr, 0, 0, nullptr, Cf, Cd, obs, BB, Ho * Wo, Cd, st)); }
                 ConvParams c2 = nhwc_conv(K(b + ".conv2"), {{Cf, Cd, Cd, obs}}, Ho, Wo, Ho, Wo, 1, 1, 1, 0, Bf, Cd, obs, EPI_NONE);
                 c2.st_partial = sc.partial;
-                CF_HIP(h, run_conv(h, c2, B, st));
-                { PROF(h, st, "enc.inorm_final", 16.0 * B * ((Ho * Wo + 31) / 32) * Cd); CF_HIP(h, launch_inorm_final(sc.partial, (Ho * Wo + 31) / 32, B, Ho * Wo, Cd, eps, sc.stats, st)); }
+                CF_HIP(h, run_conv(h, c2, BB, st));
+                { PROF(h, st, "enc.inorm_final", 16.0 * BB * nch * Cd); CF_HIP(h, launch_inorm_final(sc.partial, nch, BB, Ho * Wo, Cd, eps, sc.stats, st)); }
                 const float* res = A;
                 int res_ld = Cx;
                 long res_bs = ibs;
@@ -1163,11 +1223,12 @@ static int encoder_forward(cf_handle* h, const std::string& pre, bool bn, const 
                 if (stride != 1) {
                     ConvParams ds = nhwc_conv(K(b + ".downsample.0"), {{A, Cx, Cx, ibs}}, Hc, Wc, Ho, Wo, stride, 0, 0, 0, Cf, Cd, obs, EPI_NONE);
                     ds.st_partial = sc.partial;
-                    CF_HIP(h, run_conv(h, ds, B, st));
-                    { PROF(h, st, "enc.inorm_final", 16.0 * B * ((Ho * Wo + 31) / 32) * Cd); CF_HIP(h, launch_inorm_final(sc.partial, (Ho * Wo + 31) / 32, B, Ho * Wo, Cd, eps, sc.stats2, st)); }
+                    CF_HIP(h, run_conv(h, ds, BB, st));
+                    { PROF(h, st, "enc.inorm_final", 16.0 * BB * nch * Cd); CF_HIP(h, launch_inorm_final(sc.partial, nch, BB, Ho * Wo, Cd, eps, sc.stats2, st)); }
                     res = Cf; res_ld = Cd; res_bs = obs; res_stats = sc.stats2;
                 }
-                { PROF(h, st, "enc.inorm_apply_res", 12.0 * B * Ho * Wo * Cd); CF_HIP(h, launch_inorm_apply(Bf, Cd, obs, sc.stats, res, res_ld, res_bs, res_stats, Df, Cd, obs, B, Ho * Wo, Cd, st)); }
+                { PROF(h, st, "enc.inorm_apply_res", 12.0 * BB * Ho * Wo * Cd);
+                  CF_HIP(h, launch_inorm_apply(Bf, Cd, obs, sc.stats, res, res_ld, res_bs, res_stats, Df, Cd, obs, BB, Ho * Wo, Cd, st)); }
                 std::swap(A, Df);
             }
             Hc = Ho; Wc = Wo; Cx = Cd;
@@ -1177,13 +1238,14 @@ static int encoder_forward(cf_handle* h, const std::string& pre, bool bn, const 
     const long N = (long)Hc * Wc;
     if (!out2) {
         ConvParams c = nhwc_conv(K("conv2"), {{A, Cx, Cx, N * Cx}}, Hc, Wc, Hc, Wc, 1, 0, 0, 0, out, 256, N * 256, EPI_NONE);
-        CF_HIP(h, run_conv(h, c, B, st));
+        CF_HIP(h, run_conv(h, c, BB, st));
     } else {
+        if (nin != 1) return h->fail(CF_ERR_ARG, "encoder_forward: the split output exists for a single encoder only");
         // net, inp = split(cnet, [128,128]); tanh / relu   DCEIFlow.py:193-196
         ConvParams c = nhwc_conv(K("conv2"), {{A, Cx, Cx, N * Cx}}, Hc, Wc, Hc, Wc, 1, 0, 0, 0, out, 128, N * 128, EPI_TANH_RELU_SPLIT);
         c.split = 128;
         set_out2(c, out2, 128, N * 128);
-        CF_HIP(h, run_conv(h, c, B, st));
+        CF_HIP(h, run_conv(h, c, BB, st));
     }
     return CF_OK;
 }
@@ -1201,7 +1263,12 @@ static bool eraft_begin(cf_handle* h) {
     const bool reuse = h->reuse_next && h->fmap2_valid;
     h->reuse_next = false;
     h->fmap2_valid = false;
-    if (reuse) std::swap(h->fmap1, h->pfmap2);      // fnet(in0) == fnet(previous in1): same kernels on the same bytes
+    if (reuse) {
+        std::swap(h->fmap1, h->pfmap2);      // fnet(in0) == fnet(previous in1): same kernels on the same bytes
+    } else {                                 // both grids go through fnet as one 2B batch: old | new halves of fpair
+        h->fmap1 = h->fpair;
+        h->pfmap2 = h->fpair + (long)h->B * h->N * 256;
+    }
     return reuse;
 }
 static void eraft_done(cf_handle* h) { h->fmap2_valid = h->cfg.mode == CF_MODE_ERAFT; }
@@ -1226,18 +1293,25 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
     CF_HIP(h, hipEventRecord(h->ev_fork, st));
     CF_HIP(h, hipStreamWaitEvent(sx0, h->ev_fork, 0));
     CF_HIP(h, hipStreamWaitEvent(sx1, h->ev_fork, 0));
+    // fnet and enet (eiflow) / fnet on both voxel grids (eraft) have identical layer shapes: they run as ONE batch of 2B
+    // images on the caller's stream (every layer one launch with twice the workgroups: fewer, fuller launches than two
+    // encoders on two streams); cnet, the third encoder, runs beside them on a side stream.
     if (!eraft) {
-        if ((rc = encoder_forward(h, "event_flownet.enet", false, ev, bins, 1.f, 0.f, h->emap, nullptr, 0, st))) return rc;
-        if ((rc = encoder_forward(h, "event_flownet.fnet", false, img, 1, 2.f, -1.f, h->fmap1, nullptr, 1, sx0))) return rc;
-        if ((rc = encoder_forward(h, "event_flownet.cnet", true, img, 1, 2.f, -1.f, h->net, h->inp, 2, sx1))) return rc;
+        const EncIn pair[2] = {{img, 1, 2.f, -1.f, "event_flownet.fnet"}, {ev, bins, 1.f, 0.f, "event_flownet.enet"}};
+        const EncIn cn = {img, 1, 2.f, -1.f, "event_flownet.cnet"};
+        if ((rc = encoder_forward(h, "event_flownet.pair", false, pair, 2, h->fmap1, nullptr, 0, st))) return rc;   // fmap1 | emap
+        if ((rc = encoder_forward(h, "event_flownet.cnet", true, &cn, 1, h->net, h->inp, 2, sx1))) return rc;
     } else {
+        const EncIn cn = {img, bins, 1.f, 0.f, "event_flownet.cnet"};
         if (reuse) {
-            if ((rc = encoder_forward(h, "event_flownet.fnet", false, img, bins, 1.f, 0.f, h->pfmap2, nullptr, 1, st))) return rc;
+            const EncIn one = {img, bins, 1.f, 0.f, "event_flownet.fnet"};
+            // tiles chosen as for the 2B batch of the non-reusing frame: bit-identical feature maps either way
+            if ((rc = encoder_forward(h, "event_flownet.fnet", false, &one, 1, h->pfmap2, nullptr, 0, st, 2 * B))) return rc;
         } else {
-            if ((rc = encoder_forward(h, "event_flownet.fnet", false, ev, bins, 1.f, 0.f, h->fmap1, nullptr, 0, st))) return rc;
-            if ((rc = encoder_forward(h, "event_flownet.fnet", false, img, bins, 1.f, 0.f, h->pfmap2, nullptr, 1, sx0))) return rc;
+            const EncIn two[2] = {{ev, bins, 1.f, 0.f, "event_flownet.fnet"}, {img, bins, 1.f, 0.f, "event_flownet.fnet"}};
+            if ((rc = encoder_forward(h, "event_flownet.fnet", false, two, 2, h->fpair, nullptr, 0, st))) return rc;   // fmap(old) | fmap(new)
         }
-        if ((rc = encoder_forward(h, "event_flownet.cnet", true, img, bins, 1.f, 0.f, h->net, h->inp, 2, sx1))) return rc;
+        if ((rc = encoder_forward(h, "event_flownet.cnet", true, &cn, 1, h->net, h->inp, 2, sx1))) return rc;
     }
     // cnet-only consumers stay on its stream: iteration-invariant `inp` part of the six GRU convolutions
     for (int pass = 0; pass < 2; ++pass) {
@@ -1292,14 +1366,31 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
     // 1 while the next iteration runs.  It reads net / coords1, which the next iteration updates in place, so the main
     // stream waits for it (up_pending) right before the first such write -- by then it has long finished.
     bool up_pending = false;
-    for (int it = 0; it < iters; ++it) {
-        // corr = corr_fn(coords1); flow = coords1 - coords0
+    // FlowHead.conv2 + `coords1 += delta_flow` (with_event_updater.py:13-14, DCEIFlow.py:218) of one iteration and the
+    // correlation lookup of the next are one launch (both are per-query-pixel work on the 1/8 grid)
+    const PackedConv& fh2 = h->conv["fh.conv2"];
+    auto fh_lookup = [&](bool with_fh, bool with_lookup) -> hipError_t {
         LookupParams lp;
+        memset(&lp, 0, sizeof(lp));
         for (int l = 0; l < 4; ++l) { lp.lvl[l] = h->corr[l]; lp.lh[l] = h->clh[l]; lp.lw[l] = h->clw[l]; }
-        lp.coords1 = h->coords1; lp.out = h->corrfeat; lp.out_ld = cf_handle::CORR_LD;
-        lp.motion = h->motion; lp.mo_ld = 128; lp.mo_off = 126;
+        lp.coords1 = h->coords1;
         lp.B = B; lp.h8 = h8; lp.w8 = w8; lp.radius = 4; lp.nlevels = 4;
-        { PROF(h, st, "corr.lookup", 4.0 * B * N * (4 * 324 + cf_handle::CORR_LD)); CF_HIP(h, launch_corr_lookup(lp, st)); }
+        if (with_lookup) {
+            lp.out = h->corrfeat; lp.out_ld = cf_handle::CORR_LD;
+            lp.motion = h->motion; lp.mo_ld = 128; lp.mo_off = 126;
+        }
+        if (with_fh) {
+            lp.fh = h->fh; lp.fh_ld = 256; lp.fh_w = fh2.w; lp.fh_ktot = fh2.Ktot; lp.fh_bias = fh2.bias; lp.coords_out = h->coords1;
+        }
+        PROF(h, st, with_fh ? (with_lookup ? "fh.conv2+corr.lookup" : "fh.conv2") : "corr.lookup",
+             4.0 * B * N * ((with_lookup ? 4 * 324 + cf_handle::CORR_LD : 0) + (with_fh ? 256 + 4 : 0)));
+        return launch_corr_lookup(lp, st);
+    };
+    if (fh2.cin_pad != 256 || fh2.KH != 3 || fh2.KW != 3 || fh2.cout != 2) return h->fail(CF_ERR_WEIGHT, "flow_head.conv2 must be 3x3, 256 -> 2");
+    for (int it = 0; it < iters; ++it) {
+        // corr = corr_fn(coords1); flow = coords1 - coords0.  From the second iteration on the same launch first finishes
+        // the previous iteration: coords1 += FlowHead.conv2(fh) (see fh_lookup below)
+        if (it == 0) CF_HIP(h, fh_lookup(false, true));
         // BasicMotionEncoder  with_event_updater.py:102-112.  The flow branch (convf1 -> convf2) only needs
         // coords1, so it runs on a side stream next to lookup -> convc1 -> convc2.
         CF_HIP(h, hipEventRecord(h->ev_fork, st));
@@ -1351,10 +1442,8 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
         // FlowHead + coords1 += delta_flow   with_event_updater.py:13-14, DCEIFlow.py:218
         ConvParams h1 = nhwc_conv(h->conv["fh.conv1"], {{h->net, 128, 128, N * 128}}, h8, w8, h8, w8, 1, 1, 1, 0, h->fh, 256, N * 256, EPI_RELU);
         CF_HIP(h, run_conv(h, h1, B, st));
-        ConvParams h2 = nhwc_conv(h->conv["fh.conv2"], {{h->fh, 256, 256, N * 256}}, h8, w8, h8, w8, 1, 1, 1, 0, h->coords1, 1, 2 * N, EPI_ADD_AUX);
-        h2.out_cs = (int)N;
-        set_aux0(h2, h->coords1, 1, 2 * N, (int)N);
-        CF_HIP(h, run_conv(h, h2, B, st));
+        // FlowHead.conv2 + coords1 += delta_flow, fused with the next iteration's lookup (nothing follows the last one)
+        CF_HIP(h, fh_lookup(true, it + 1 < iters));
         const bool last = it == iters - 1;
         float* up = flow_preds ? flow_preds + (long)it * B * 2 * h->Hp * h->Wp : nullptr;
         hipStream_t su = st;
@@ -1586,7 +1675,7 @@ extern "C" int cf_graph_enable(cf_handle* h, int on) {
 
 // replays / captures / runs eagerly; returns CF_OK or an error code
 static int step_dispatch(cf_handle* h, const StepArgs& a, bool reuse, hipStream_t st) {
-    bool use = h->graph_on && !h->prof && !h->phases && !h->serial;
+    bool use = h->graph_on && !h->prof && !h->phases && (!h->serial || h->graph_serial);
     if (use && st) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) use = false;
@@ -1847,6 +1936,7 @@ extern "C" int cf_op_corr_lookup(const float* fmap1, const float* fmap2, const f
     for (int l = 1; l < 4; ++l)
         if (launch_corr_pool(static_cast<float*>(lv[l - 1].p), static_cast<float*>(lv[l].p), (long)B * N, lh[l - 1], lw[l - 1], st) != hipSuccess) return CF_ERR_HIP;
     LookupParams lp;
+    memset(&lp, 0, sizeof(lp));
     for (int l = 0; l < 4; ++l) { lp.lvl[l] = static_cast<float*>(lv[l].p); lp.lh[l] = lh[l]; lp.lw[l] = lw[l]; }
     lp.coords1 = coords; lp.out = out; lp.out_ld = 324; lp.motion = nullptr; lp.mo_ld = 0; lp.mo_off = 0;
     lp.B = B; lp.h8 = hh; lp.w8 = ww; lp.radius = 4; lp.nlevels = 4;

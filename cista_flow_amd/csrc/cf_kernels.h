@@ -75,7 +75,10 @@ struct ConvParams {
     // ---- B operand (packed weights [w_rows][Ktot], K contiguous) ----
     const float* w;
     const void* w16;    // f16 split copy of w (nullable; f16 modes fall back to splitting B while staging)
-    long w_bs;          // batch stride (0 for ordinary weights; N*D for the correlation GEMM)
+    long w_bs;          // weight stride between image groups (0 for ordinary weights; N*D for the correlation GEMM)
+    int  w_div;         // images per weight group (<= 1: one matrix per image when w_bs != 0).  Two networks with the
+                        // same layer shapes run as ONE launch over a 2B batch: images [0,B) use matrix 0, [B,2B) matrix 1
+    long bias_gs;       // bias stride between the same groups (floats)
     int  w_rows;        // valid rows in the packed matrix
     int  Ktot;          // taps * cin_pad (A_NHWC/A_UPS2X) or round16(taps*Cin) (A_GATHER)
     int  cin_pad;       // per-tap K (multiple of 16); unused for A_GATHER
@@ -102,6 +105,8 @@ struct ConvParams {
     // {sum, sum of squares} of v = acc + bias to st_partial[b][ceil(M/32)][cout][2]; launch_inorm_final folds them
     double* st_partial;
     long long* stamp;   // -DCF_STAMP builds only (tools/stamp_probe.py): per-wave cycle stamps of conv_dma_kernel
+    int  tile_batch;    // > 0: choose the tile as if the batch were this large (keeps the arithmetic order of a launch that
+                        // covers only part of a batch identical to the full-batch launch: ERAFT feature reuse)
     int  epi_vec;       // set by launch_conv: out / out2 / aux / addend rows are 16-byte aligned (dwordx4 tail)
 };
 
@@ -166,9 +171,14 @@ hipError_t launch_corr_pool(const float* src, float* dst, long rows, int Hs, int
 struct LookupParams {
     const float* lvl[4]; int lh[4], lw[4];
     const float* coords1;       // planar [B][2][h8][w8]
-    float* out; int out_ld;
+    float* out; int out_ld;     // nullptr: no lookup (the flow-head step alone, after the last iteration)
     float* motion; int mo_ld; int mo_off;
     int B, h8, w8, radius, nlevels;
+    // optional fused step in front of the lookup: coords1 += FlowHead.conv2(fh) (3x3, 256 -> 2, zero pad) at every query
+    const float* fh; int fh_ld;             // nullptr: lookup at coords1 as it is; NHWC [B][N][256]
+    const float* fh_w; int fh_ktot;         // packed rows 0 / 1 of [rows][9 * 256] (k = tap * 256 + c)
+    const float* fh_bias;
+    float* coords_out;                      // = coords1 (in place: a query only reads and writes its own pixel)
 };
 hipError_t launch_corr_lookup(const LookupParams& p, hipStream_t s);
 

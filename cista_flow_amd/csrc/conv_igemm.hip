@@ -75,6 +75,9 @@ __device__ __forceinline__ const float* sel3(const float* const (&a)[3], int s) 
 }
 
 
+// weight / bias group of image b (ConvParams::w_div)
+__device__ __forceinline__ int wgroup(const ConvParams& p, int b) { return p.w_div > 1 ? b / p.w_div : b; }
+
 static constexpr int EPI_S = 36;   // per-wave epilogue patch row stride (floats)
 
 // Element-wise tail of one conv output quad: pixel m, couts n..n+3 (n % 4 == 0).
@@ -83,8 +86,9 @@ __device__ __forceinline__ void epilogue4(const ConvParams& p, int b, int m, int
     const bool full = nv == 4;
     f32x4 v = acc;
     if (p.bias) {
+        const float* bias = p.bias + (long)wgroup(p, b) * p.bias_gs;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += (e < nv) ? p.bias[n + e] : 0.f;
+        for (int e = 0; e < 4; ++e) v[e] += (e < nv) ? bias[n + e] : 0.f;
     }
     if (p.addend) {   // iteration-invariant part of a linear layer, precomputed once per frame
         const long aoff = (long)b * p.addend_bs + (long)m * p.addend_ld + n;
@@ -262,7 +266,7 @@ __device__ __forceinline__ void patch_tail_fast(const ConvParams& p, const float
     const int mb = mrow0 + (lane >> 3);
     const int epi = p.epi;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, lam4 = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) bias4 = buf_load4(make_rsrc(p.bias), 4u * (unsigned)n, 0);
+    if (p.bias) bias4 = buf_load4(make_rsrc(p.bias + (long)wgroup(p, b) * p.bias_gs), 4u * (unsigned)n, 0);
     if (epi == EPI_ADD_AUX_SHRINK) lam4 = buf_load4(make_rsrc(p.lam), 4u * (unsigned)n, 0);
     const bool has_add = p.addend != nullptr;
     // descriptors of absent tensors are built from null + offset and never used (a pointer select here makes
@@ -501,7 +505,7 @@ __device__ __forceinline__ void patch_stats(const ConvParams& p, const float* sW
     const int c = lane & 31, half = lane >> 5;
     const int n = nbase + c;
     const int nvalid = M - mrow0;          // rows of this patch inside the image (<= 0: patch is all padding)
-    const float bv = (p.bias && n < p.cout) ? p.bias[n] : 0.f;
+    const float bv = (p.bias && n < p.cout) ? p.bias[(long)wgroup(p, b) * p.bias_gs + n] : 0.f;
     double s = 0.0, ss = 0.0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -614,7 +618,7 @@ __global__ __launch_bounds__(256, igemm_waves(BM, BN, WAVES_M, WAVES_N, WK, KCW)
     unsigned b_off[B_IT];
     bool b_live[B_IT];
     int b_row[B_IT], b_q[B_IT];
-    const __amdgpu_buffer_rsrc_t b_rsrc = make_rsrc(p.w + (long)b * p.w_bs);
+    const __amdgpu_buffer_rsrc_t b_rsrc = make_rsrc(p.w + (long)wgroup(p, b) * p.w_bs);
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
         const int slot = tid + 256 * it;
@@ -1121,7 +1125,7 @@ void conv_dma_kernel(const ConvParams p) {
     }
     unsigned b_off[B_IT];
     bool b_use[B_IT];
-    const __amdgpu_buffer_rsrc_t b_rsrc = make_rsrc(p.w + (long)b * p.w_bs);
+    const __amdgpu_buffer_rsrc_t b_rsrc = make_rsrc(p.w + (long)wgroup(p, b) * p.w_bs);
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
         const int slot = tid + 256 * it;
@@ -1581,7 +1585,7 @@ static int default_small3x3() {
 }
 
 static bool smalln_ok(const ConvParams& p) {
-    if (p.a_mode != A_NHWC || p.nseg != 1 || p.cout > 2 || p.w_bs != 0) return false;
+    if (p.a_mode != A_NHWC || p.nseg != 1 || p.cout > 2 || p.w_bs != 0 || p.bias_gs != 0) return false;
     if (p.cin_pad != 64 && p.cin_pad != 128 && p.cin_pad != 256) return false;
     return p.epi == EPI_NONE || p.epi == EPI_SIGMOID || p.epi == EPI_RELU || p.epi == EPI_TANH || p.epi == EPI_ADD_AUX;
 }
@@ -1737,7 +1741,8 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
         // MI355X): big tiles reuse operands best, but a launch with fewer than ~512 workgroups leaves CUs idle,
         // so small-M layers step down to 64x64 and then to the intra-workgroup split-K tiles (32x64, 32x32).
         const long M = (long)p.Ho * p.Wo;
-        auto wgs = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((p.cout + bn - 1) / bn) * batch; };
+        const long tb = p.tile_batch > 0 ? p.tile_batch : batch;
+        auto wgs = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((p.cout + bn - 1) / bn) * tb; };
         const long FILL = 512;
         if (p.cout <= 32) {
             tile = (wgs(128, 32) >= FILL || !splitk_ok(p, 4)) ? 6 : 8;
@@ -1758,7 +1763,7 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
     }
     if (tile == 0) return hipErrorInvalidValue;
     if (auto_tile) {
-        const long wgs128x128 = (((long)p.Ho * p.Wo + 127) / 128) * ((p.cout + 127) / 128) * batch;
+        const long wgs128x128 = (((long)p.Ho * p.Wo + 127) / 128) * ((p.cout + 127) / 128) * (p.tile_batch > 0 ? p.tile_batch : batch);
         // wide stages (32 k-columns per wave between barriers) measured 3-8 % faster wherever the channel
         // segments allow them (tools/conv_bench.py, MI355X)
         if (tile == 9 && stage_ok(p, 64)) tile = 10;
@@ -1786,7 +1791,7 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
     g_last_launch.kernel = conv_tile_name(tile);
     if (p.prec != 0 && p.prec != 1 && p.prec != 3) return hipErrorInvalidValue;
     if (p.prec != 0) {          // f16 modes: pre-split weights when there are some, else split B while staging
-        if (p.w16 && p.w_bs == 0) {
+        if (p.w16 && (p.w_bs == 0 || p.w_div > 1)) {
             p.w = static_cast<const float*>(p.w16);
             p.b_f32 = 0;
         } else {

@@ -436,59 +436,103 @@ hipError_t launch_corr_pool(const float* src, float* dst, long rows, int Hs, int
 }
 
 // ---------------------------------------------------------------------------
-// correlation lookup (a10): raft_corr.py:32-54 + sample_utils.py:38-52.
-// channel lvl*(2r+1)^2 + a*(2r+1) + bb  =  zero-padded bilinear sample of level lvl at
-// (x/2^lvl + a - r, y/2^lvl + bb - r).  One wave per query pixel, lanes over channels.
+// correlation lookup (a10): raft_corr.py:32-54 + sample_utils.py:38-52, with FlowHead.conv2 and `coords1 += delta`
+// of the PREVIOUS refinement iteration fused in front of it (with_event_updater.py:13-14, DCEIFlow.py:218): both are
+// per-query-pixel work on the 1/8-resolution grid and sat on the iteration's critical path as three tiny launches.
+//
+// channel lvl*81 + a*9 + bb = zero-padded bilinear sample of level lvl at (x/2^lvl + a - 4, y/2^lvl + bb - 4).  The 81
+// samples of a level differ by INTEGER offsets, so they share one pair of fractional weights and one 10x10 grid of
+// integer taps: a wave (= one query pixel) loads the 100 taps of a level into its LDS patch (2 loads per lane) and every
+// output is a 4-term blend of neighbouring patch entries -- 8 global loads per lane and query instead of 24, no
+// per-channel coordinate arithmetic.
+// FlowHead.conv2 (3x3, 256 -> 2, zero pad): lanes split the 256 channels (16-byte loads), 9 taps, wave reduction.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void corr_lookup_kernel(const LookupParams p) {
+    __shared__ float patch[4][4][104];          // [wave][level][10x10 taps]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const long N = (long)p.h8 * p.w8;
+    const int N = p.h8 * p.w8;
     const long qid = (long)blockIdx.x * 4 + wave;
     if (qid >= (long)p.B * N) return;
     const int b = (int)(qid / N);
-    const int i = (int)(qid % N);
-    const int qy = i / p.w8, qx = i % p.w8;
-    const float cx = p.coords1[((long)b * 2 + 0) * N + i];
-    const float cy = p.coords1[((long)b * 2 + 1) * N + i];
-    const int d = 2 * p.radius + 1;
-    const int per = d * d;
-    const int nch = p.nlevels * per;
-    float* o = p.out + ((long)b * N + i) * p.out_ld;
-    for (int ch = lane; ch < p.out_ld; ch += 64) {
-        float val = 0.f;
-        if (ch < nch) {
-            const int lvl = ch / per;
-            const int rem = ch - lvl * per;
-            const int a = rem / d, bb = rem - a * d;
-            const int Hl = lvl == 0 ? p.lh[0] : (lvl == 1 ? p.lh[1] : (lvl == 2 ? p.lh[2] : p.lh[3]));
-            const int Wl = lvl == 0 ? p.lw[0] : (lvl == 1 ? p.lw[1] : (lvl == 2 ? p.lw[2] : p.lw[3]));
-            const float* base = lvl == 0 ? p.lvl[0] : (lvl == 1 ? p.lvl[1] : (lvl == 2 ? p.lvl[2] : p.lvl[3]));
-            const float* plane = base + ((long)b * N + i) * Hl * Wl;
-            const float div = (float)(1 << lvl);
-            const float x = cx / div + (float)(a - p.radius);
-            const float y = cy / div + (float)(bb - p.radius);
-            // bilinear_sampler: g = 2*x/(W-1) - 1 ; grid_sample(align_corners=True): (g+1)*((W-1)/2)
-            const float gx = 2.f * x / (float)(Wl - 1) - 1.f;
-            const float gy = 2.f * y / (float)(Hl - 1) - 1.f;
-            const float ix = (gx + 1.f) * ((float)(Wl - 1) / 2.f);
-            const float iy = (gy + 1.f) * ((float)(Hl - 1) / 2.f);
-            const float fx = floorf(ix), fy = floorf(iy);
-            const float tx = ix - fx, ty = iy - fy;
-            // float compare before the int cast keeps huge / NaN coordinates out of range
-            const bool inx0 = fx >= 0.f && fx <= (float)(Wl - 1);
-            const bool inx1 = fx + 1.f >= 0.f && fx + 1.f <= (float)(Wl - 1);
-            const bool iny0 = fy >= 0.f && fy <= (float)(Hl - 1);
-            const bool iny1 = fy + 1.f >= 0.f && fy + 1.f <= (float)(Hl - 1);
-            const int x0 = inx0 ? (int)fx : 0, x1 = inx1 ? (int)fx + 1 : 0;
-            const int y0 = iny0 ? (int)fy : 0, y1 = iny1 ? (int)fy + 1 : 0;
-            const float v00 = (inx0 && iny0) ? plane[(long)y0 * Wl + x0] : 0.f;
-            const float v01 = (inx1 && iny0) ? plane[(long)y0 * Wl + x1] : 0.f;
-            const float v10 = (inx0 && iny1) ? plane[(long)y1 * Wl + x0] : 0.f;
-            const float v11 = (inx1 && iny1) ? plane[(long)y1 * Wl + x1] : 0.f;
-            val = v00 * ((1.f - tx) * (1.f - ty)) + v01 * (tx * (1.f - ty)) + v10 * ((1.f - tx) * ty) + v11 * (tx * ty);
+    const int i = (int)(qid - (long)b * N);
+    const int qy = i / p.w8, qx = i - qy * p.w8;
+    float cx = p.coords1[((long)b * 2 + 0) * N + i];
+    float cy = p.coords1[((long)b * 2 + 1) * N + i];
+    if (p.fh) {
+        // delta_flow = FlowHead.conv2(relu(conv1(net))) at this pixel; coords1 += delta_flow
+        float a0 = 0.f, a1 = 0.f;
+        const int c0 = lane * 4;                 // 64 lanes x 4 channels = 256
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = qy + t / 3 - 1, xx = qx + t % 3 - 1;
+            if (yy < 0 || yy >= p.h8 || xx < 0 || xx >= p.w8) continue;      // wave-uniform
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p.fh + ((long)b * N + (long)yy * p.w8 + xx) * p.fh_ld + c0);
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(p.fh_w + (long)t * p.fh_ld + c0);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(p.fh_w + (long)p.fh_ktot + (long)t * p.fh_ld + c0);
+            a0 += v[0] * w0[0] + v[1] * w0[1] + v[2] * w0[2] + v[3] * w0[3];
+            a1 += v[0] * w1[0] + v[1] * w1[1] + v[2] * w1[2] + v[3] * w1[3];
         }
-        o[ch] = val;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            a0 += __shfl_xor(a0, off);
+            a1 += __shfl_xor(a1, off);
+        }
+        cx = (a0 + p.fh_bias[0]) + cx;           // conv output (+ bias) + aux, as the stand-alone conv tail orders it
+        cy = (a1 + p.fh_bias[1]) + cy;
+        if (lane == 0) {
+            p.coords_out[((long)b * 2 + 0) * N + i] = cx;
+            p.coords_out[((long)b * 2 + 1) * N + i] = cy;
+        }
     }
+    if (!p.out) return;
+    // ---- taps: level l, lane -> tap (ty, tx) of the 10x10 grid, two passes ----
+    float tx[4], ty[4];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        if (l >= p.nlevels) break;
+        const int Hl = p.lh[l], Wl = p.lw[l];
+        const float* plane = p.lvl[l] + ((long)b * N + i) * Hl * Wl;
+        const float div = (float)(1 << l);
+        // bilinear_sampler: g = 2*x/(W-1) - 1 ; grid_sample(align_corners=True): (g+1)*((W-1)/2) -- evaluated for the
+        // window's first sample (offset -4); the other 80 are at exact integer distances from it
+        const float x0s = cx / div + (float)(-p.radius), y0s = cy / div + (float)(-p.radius);
+        const float gx = 2.f * x0s / (float)(Wl - 1) - 1.f, gy = 2.f * y0s / (float)(Hl - 1) - 1.f;
+        const float ix = (gx + 1.f) * ((float)(Wl - 1) / 2.f), iy = (gy + 1.f) * ((float)(Hl - 1) / 2.f);
+        const float fx = floorf(ix), fy = floorf(iy);
+        tx[l] = ix - fx;
+        ty[l] = iy - fy;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int t = lane + 64 * k;
+            if (t < 100) {
+                const int tr = t / 10, tc = t - tr * 10;
+                const float xf = fx + (float)tc, yf = fy + (float)tr;
+                // float compare before the int cast keeps huge / NaN coordinates out of range
+                const bool ok = xf >= 0.f && xf <= (float)(Wl - 1) && yf >= 0.f && yf <= (float)(Hl - 1);
+                patch[wave][l][t] = ok ? plane[(long)(int)yf * Wl + (int)xf] : 0.f;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int d = 2 * p.radius + 1;          // 9
+    float* o = p.out + ((long)b * N + i) * p.out_ld;
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+        if (l >= p.nlevels) break;
+        const float w00 = (1.f - tx[l]) * (1.f - ty[l]), w01 = tx[l] * (1.f - ty[l]), w10 = (1.f - tx[l]) * ty[l], w11 = tx[l] * ty[l];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int ch = lane + 64 * k;
+            if (ch < d * d) {
+                const int a = ch / d, bb = ch - a * d;          // a steps x, bb steps y (RAFT's transposed window)
+                const float* t0 = &patch[wave][l][bb * 10 + a];
+                o[l * d * d + ch] = t0[0] * w00 + t0[1] * w01 + t0[10] * w10 + t0[11] * w11;
+            }
+        }
+    }
+    for (int ch = p.nlevels * d * d + lane; ch < p.out_ld; ch += 64) o[ch] = 0.f;      // pad channels of the concat buffer
     if (p.motion && lane < 2) {
         // flow = coords1 - coords0 ; coords0 = pixel grid (sample_utils.py:55-58)
         const float f = lane == 0 ? (cx - (float)qx) : (cy - (float)qy);
@@ -497,11 +541,20 @@ __global__ __launch_bounds__(256) void corr_lookup_kernel(const LookupParams p) 
 }
 
 hipError_t launch_corr_lookup(const LookupParams& p, hipStream_t s) {
-    if (p.nlevels < 1 || p.nlevels > 4 || p.radius < 0 || !p.out || !p.coords1) return hipErrorInvalidValue;
+    if (p.nlevels < 1 || p.nlevels > 4 || p.radius != 4 || !p.coords1) return hipErrorInvalidValue;
     const int d = 2 * p.radius + 1;
-    if (p.out_ld < p.nlevels * d * d) return hipErrorInvalidValue;
-    for (int l = 0; l < p.nlevels; ++l)
-        if (!p.lvl[l] || p.lh[l] < 2 || p.lw[l] < 2) return hipErrorInvalidValue;
+    if (p.out) {
+        if (p.out_ld < p.nlevels * d * d) return hipErrorInvalidValue;
+        for (int l = 0; l < p.nlevels; ++l)
+            if (!p.lvl[l] || p.lh[l] < 2 || p.lw[l] < 2) return hipErrorInvalidValue;
+    }
+    if (p.fh) {
+        if (!p.fh_w || !p.fh_bias || !p.coords_out || p.fh_ld != 256 || p.fh_ktot != 9 * 256 ||
+            ((reinterpret_cast<uintptr_t>(p.fh) | reinterpret_cast<uintptr_t>(p.fh_w)) & 15) != 0)
+            return hipErrorInvalidValue;
+    } else if (!p.out) {
+        return hipErrorInvalidValue;
+    }
     const long nq = (long)p.B * p.h8 * p.w8;
     note_launch("corr_lookup_kernel", dim3((unsigned)((nq + 3) / 4)), dim3(256));
     hipLaunchKernelGGL(corr_lookup_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, p);

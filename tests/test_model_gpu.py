@@ -526,15 +526,17 @@ def test_graph_replay_is_bit_identical(gpu, kind):
             m.reuse_prev_features = True
         h = m._be().get(B, gpu)
         h.graph_enable(graph)
-        evs = [wu.synth_events(B, 5, H, W, 300 + t).to(gpu) for t in range(4)]
+        # two alternating voxel-grid buffers x the allocator's own period: a handful of distinct pointer tuples, each
+        # captured on its second sighting
+        evs = [wu.synth_events(B, 5, H, W, 300 + t).to(gpu) for t in range(2)]
         states, prev, flow_init, outs = None, torch.zeros(B, 1, H, W, device=gpu), None, []
         with torch.no_grad():
-            for t in range(14):
-                ev = evs[t % 4]
+            for t in range(24):
+                ev = evs[t % 2]
                 if kind == "eiflow":
                     I, bf, states = m({"event_voxel": ev, "rec_img0": prev}, states, {})
                 elif kind == "eraft":
-                    I, bf, states = m({"event_voxel": ev, "event_voxel_old": evs[(t - 1) % 4], "rec_img0": prev}, states, {})
+                    I, bf, states = m({"event_voxel": ev, "event_voxel_old": evs[(t - 1) % 2], "rec_img0": prev}, states, {})
                 else:
                     I, bf, states = m({"event_voxel": ev, "rec_img0": prev}, states, flow_init, {})
                     flow_init = bf["next_flow"]
