@@ -188,13 +188,26 @@ def main():
     # CF_BENCH_REHEARSE=1: control-flow rehearsal of the N > 1 path on a box with ONE GPU (all ranks share cuda:0,
     # collectives go through gloo on host tensors).  Numbers from it mean nothing; it exists because the real
     # RCCL run only happens on the driver's 8-GPU node.
-    rehearse = os.environ.get("CF_BENCH_REHEARSE") == "1"
-    dev = torch.device("cuda", 0 if rehearse else local_rank)
+    # CF_BENCH_REHEARSE=nccl: the same with the REAL backend -- init_process_group("nccl", device_id=cuda:0) on every rank
+    # and device-side all_gather_into_tensor on the side stream -- where RCCL accepts two ranks on one device.
+    rmode = os.environ.get("CF_BENCH_REHEARSE", "")
+    rehearse = rmode == "1"                       # gloo + host tensors
+    shared = rmode in ("1", "nccl")               # all ranks share cuda:0
+    dev = torch.device("cuda", 0 if shared else local_rank)
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    # CF_BENCH_FORCE_DIST=1: run the N > 1 code path (RCCL process group, side-stream all_gather_into_tensor with
+    # record_stream, barriers, MAX all-reduce) with a world of ONE rank: RCCL refuses two ranks on one device
+    # ("Duplicate GPU detected"), so this is as much of the real backend as a one-GPU box can exercise
+    force_dist = os.environ.get("CF_BENCH_FORCE_DIST") == "1" and world == 1
+    dist_on = world > 1 or force_dist
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if force_dist:
+            os.environ.setdefault("MASTER_PORT", "29577")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if rehearse:
             dist.init_process_group("gloo")
         else:
@@ -217,7 +230,7 @@ def main():
         model.reuse_prev_features = True
     R = 8
     evs = [wu.synth_events(B, 5, H, W, 1234 + 100 * rank + i).to(dev) for i in range(R)]
-    side = torch.cuda.Stream(device=dev) if world > 1 else None
+    side = torch.cuda.Stream(device=dev) if dist_on else None
 
     state = {"prev": torch.zeros(B, 1, H, W, device=dev), "states": None, "i": 0, "flow_init": None}
 
@@ -233,32 +246,32 @@ def main():
             state["flow_init"] = bf["next_flow"]
         state["prev"], state["states"] = I, st
         state["i"] += 1
-        if world > 1 and gather:
+        if dist_on and gather:
             # collate the reconstructed frames of all ranks (RCCL all-gather over xGMI) off the critical path
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 I.record_stream(side)          # I was allocated on the main stream; keep it alive for the gather
-                state["gathered"] = collate_frames(I.cpu() if rehearse else I)
+                state["gathered"] = collate_frames(I.cpu() if rehearse else I, force=force_dist)
         return I
 
     with torch.no_grad():
         for _ in range(max(a.warmup, 0)):
             step()
-        if world > 1:
+        if dist_on:
             torch.cuda.current_stream().wait_stream(side)
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(a.steps):
             step()
-        if world > 1:
+        if dist_on:
             torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([el], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
@@ -332,7 +345,9 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "alt_precision": alt,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
+        if force_dist:
+            assert state["gathered"].shape == state["prev"].shape and torch.equal(state["gathered"], state["prev"])
         dist.barrier()          # rank 0 may still be in its roofline / printing leg
         dist.destroy_process_group()
 

@@ -840,8 +840,11 @@ extern "C" int cf_create(cf_handle** out, const cf_config* cfg) {
     ok = ok && hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&h->ev_g[0], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&h->ev_g[1], hipEventDisableTiming) == hipSuccess;
-    // CF_GRAPH=0|1 overrides the default (host time per step)
-    h->graph_on = true;
+    // Opt-in (CF_GRAPH=1 / cf_graph_enable): measured on MI355X (r02) hipGraphLaunch of this
+    // multi-stream graph costs the host about as much as the eager launches (2.1 vs 2.3 ms per step) and the GPU side is
+    // unchanged, so bench.py throughput is equal or 1-4 % lower at every batch size; captured as ONE chain
+    // (CF_GRAPH_SERIAL=1) the host cost drops to 0.16 ms per step but the kernels lose their side-stream overlap.
+    h->graph_on = false;
     if (const char* e = getenv("CF_GRAPH")) h->graph_on = atoi(e) != 0;
     if (const char* e = getenv("CF_GRAPH_SERIAL")) {
         h->graph_serial = atoi(e) != 0;
@@ -1977,6 +1980,14 @@ extern "C" int cf_events_to_voxel(const double* events, const int64_t* offsets, 
     static_assert(sizeof(long) == sizeof(int64_t), "LP64");
     return launch_events_to_voxel(events, reinterpret_cast<const long*>(offsets), B, bins, H, W, voxel, stats_scratch,
                                   normalize, static_cast<hipStream_t>(stream)) == hipSuccess ? CF_OK : CF_ERR_HIP;
+}
+
+// f-4: the same with event_preprocess's hot-pixel filter (filter_hot_pixel=True zeroes |v| > 25 / num_bins before the
+// normalisation, event_process.py:196-198); hot_pixel_threshold <= 0: off
+extern "C" int cf_events_to_voxel_ex(const double* events, const int64_t* offsets, int B, int bins, int H, int W, float* voxel,
+                                     double* stats_scratch, int normalize, float hot_pixel_threshold, void* stream) {
+    return launch_events_to_voxel(events, reinterpret_cast<const long*>(offsets), B, bins, H, W, voxel, stats_scratch, normalize,
+                                  static_cast<hipStream_t>(stream), hot_pixel_threshold) == hipSuccess ? CF_OK : CF_ERR_HIP;
 }
 
 extern "C" int cf_op_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, void* stream) {

@@ -208,8 +208,9 @@ hipError_t launch_idn_deblur(const float* bins, const float* flow, float* out, i
 // f-1: events -> temporal-bilinear voxel grid + non-zero mean/std normalisation
 // (utils/event_process.py:15-72,193-216).  events: [total][4] fp64 rows (t, x, y, polarity), sequences
 // concatenated, offsets[B+1]; voxel: [B][bins][H][W] fp32 (zeroed here); stats: [B][3] fp64 scratch.
+// hot > 0: voxels with |v| > hot are zeroed before the normalisation (event_preprocess(filter_hot_pixel=True): 25 / bins)
 hipError_t launch_events_to_voxel(const double* events, const long* offsets, int B, int bins, int H, int W,
-                                  float* voxel, double* stats, int normalize, hipStream_t s);
+                                  float* voxel, double* stats, int normalize, hipStream_t s, float hot = 0.f);
 
 // layout helpers for the Python boundary / tests
 hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int dst_ld, int B, int C, int HW, hipStream_t s);

@@ -804,13 +804,17 @@ __global__ void events_scatter_kernel(const double* __restrict__ ev, const long*
 }
 
 // stats[b] = {count of non-zeros, sum, sum of squares} (fp64)
-__global__ void voxel_stats_kernel(const float* __restrict__ voxel, long per_seq, double* __restrict__ stats) {
+// hot > 0: `event_voxel_grid[abs(event_voxel_grid) > 25./num_bins] = 0` first (event_preprocess(filter_hot_pixel=True),
+// event_process.py:196-198)
+__global__ void voxel_stats_kernel(const float* __restrict__ voxel, long per_seq, double* __restrict__ stats, float hot) {
     __shared__ double sh[3][256];
     const int b = blockIdx.y;
     const float* v = voxel + (long)b * per_seq;
     double c = 0, s = 0, ss = 0;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per_seq; i += (long)gridDim.x * blockDim.x) {
-        const double x = (double)v[i];
+        float xf = v[i];
+        if (hot > 0.f && fabsf(xf) > hot) xf = 0.f;
+        const double x = (double)xf;
         if (x != 0) c += 1.0;
         s += x;
         ss += x * x;
@@ -826,21 +830,22 @@ __global__ void voxel_stats_kernel(const float* __restrict__ voxel, long per_seq
         for (int k = 0; k < 3; ++k) atomicAdd(stats + b * 3 + k, sh[k][0]);
 }
 
-__global__ void voxel_normalize_kernel(float* __restrict__ voxel, long per_seq, const double* __restrict__ stats) {
+__global__ void voxel_normalize_kernel(float* __restrict__ voxel, long per_seq, const double* __restrict__ stats, float hot) {
     const int b = blockIdx.y;
     const double cnt = stats[b * 3 + 0];
-    if (cnt <= 0) return;
-    const double mean = stats[b * 3 + 1] / cnt;
-    const double sd = sqrt(stats[b * 3 + 2] / cnt - mean * mean);
+    if (cnt <= 0 && !(hot > 0.f)) return;
+    const double mean = cnt > 0 ? stats[b * 3 + 1] / cnt : 0.0;
+    const double sd = cnt > 0 ? sqrt(stats[b * 3 + 2] / cnt - mean * mean) : 1.0;
     float* v = voxel + (long)b * per_seq;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per_seq; i += (long)gridDim.x * blockDim.x) {
         const float x = v[i];
-        if (x != 0.f) v[i] = (float)(((double)x - mean) / (sd + 1e-8));
+        if (hot > 0.f && fabsf(x) > hot) v[i] = 0.f;
+        else if (x != 0.f && cnt > 0) v[i] = (float)(((double)x - mean) / (sd + 1e-8));
     }
 }
 
 hipError_t launch_events_to_voxel(const double* events, const long* offsets, int B, int bins, int H, int W, float* voxel,
-                                  double* stats, int normalize, hipStream_t s) {
+                                  double* stats, int normalize, hipStream_t s, float hot) {
     if (!events || !offsets || !voxel || B <= 0 || bins <= 0 || H <= 0 || W <= 0 || (normalize && !stats))
         return hipErrorInvalidValue;
     const long per_seq = (long)bins * H * W;
@@ -852,9 +857,9 @@ hipError_t launch_events_to_voxel(const double* events, const long* offsets, int
         e = hipMemsetAsync(stats, 0, sizeof(double) * 3 * B, s);
         if (e != hipSuccess) return e;
         note_launch("voxel_stats_kernel", dim3(64, B), dim3(256));
-        hipLaunchKernelGGL(voxel_stats_kernel, dim3(64, B), dim3(256), 0, s, voxel, per_seq, stats);
+        hipLaunchKernelGGL(voxel_stats_kernel, dim3(64, B), dim3(256), 0, s, voxel, per_seq, stats, hot);
         note_launch("voxel_normalize_kernel", dim3(64, B), dim3(256));
-        hipLaunchKernelGGL(voxel_normalize_kernel, dim3(64, B), dim3(256), 0, s, voxel, per_seq, stats);
+        hipLaunchKernelGGL(voxel_normalize_kernel, dim3(64, B), dim3(256), 0, s, voxel, per_seq, stats, hot);
     }
     return hipGetLastError();
 }

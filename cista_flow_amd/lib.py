@@ -21,7 +21,7 @@ SYMBOLS = [
     "cf_op_conv2d", "cf_op_instance_norm_relu", "cf_op_corr_lookup", "cf_op_nchw_to_nhwc",
     "cf_op_nhwc_to_nchw", "cf_profile_enable", "cf_profile_read", "cf_conv_tile_name", "cf_profile_report", "cf_op_conv2d_bench", "cf_events_to_voxel", "cf_op_conv2d_inorm_stats", "cf_quantize_u8", "cf_hint_prev_grid",
     "cf_profile_report_json", "cf_metrics_scratch_doubles", "cf_metrics_recon", "cf_metrics_flow", "cf_metrics_fwl",
-    "cf_graph_enable", "cf_graph_stats",
+    "cf_graph_enable", "cf_graph_stats", "cf_events_to_voxel_ex",
 ]
 
 
@@ -87,6 +87,8 @@ def load():
     lib.cf_op_nhwc_to_nchw.restype = i
     lib.cf_events_to_voxel.argtypes = [fp, fp, i, i, i, i, fp, fp, i, vp]
     lib.cf_events_to_voxel.restype = i
+    lib.cf_events_to_voxel_ex.argtypes = [fp, fp, i, i, i, i, fp, fp, i, C.c_float, vp]
+    lib.cf_events_to_voxel_ex.restype = i
     lib.cf_quantize_u8.argtypes = [fp, fp, C.c_longlong, vp]
     lib.cf_quantize_u8.restype = i
     lib.cf_metrics_scratch_doubles.argtypes = []
@@ -178,7 +180,7 @@ class Handle:
         del keep
 
     def graph_enable(self, on=True):
-        """hipGraph replay of cf_step (default on unless CF_GRAPH=0)."""
+        """hipGraph replay of cf_step (opt-in; CF_GRAPH=1 sets the default)."""
         self.check(self.lib.cf_graph_enable(self.h, 1 if on else 0), "cf_graph_enable")
 
     def graph_stats(self):

@@ -14,7 +14,7 @@ def shard_range(n_sequences, rank, world):
     return start, start + base + (1 if rank < extra else 0)
 
 
-def collate_frames(local_frames, n_sequences=None, group=None):
+def collate_frames(local_frames, n_sequences=None, group=None, force=False):
     """all-gather per-rank frames [B_local, 1, H, W] -> [sum B_local, 1, H, W] in rank order.
 
     Equal shards use one all_gather_into_tensor; ragged shards (n_sequences % world != 0) pad to the largest
@@ -22,7 +22,7 @@ def collate_frames(local_frames, n_sequences=None, group=None):
     if not (dist.is_available() and dist.is_initialized()):
         return local_frames
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force:      # force: run the collective even for one rank (backend smoke test)
         return local_frames
     B = local_frames.shape[0]
     if n_sequences is None or n_sequences % world == 0:

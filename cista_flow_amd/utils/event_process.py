@@ -7,8 +7,9 @@ import torch
 from .. import lib as _lib
 
 
-def events_to_voxel_grid_batch(event_list, num_bins, width, height, normalize=True):
+def events_to_voxel_grid_batch(event_list, num_bins, width, height, normalize=True, filter_hot_pixel=False):
     """event_list: B tensors [N_b, 4] float64 on the GPU, rows (timestamp, x, y, polarity) in time order.
+    filter_hot_pixel: event_preprocess(filter_hot_pixel=True) -- zero voxels with |v| > 25 / num_bins before normalising.
     Returns [B, num_bins, height, width] float32."""
     if len(event_list) == 0:
         raise ValueError("empty batch")
@@ -28,8 +29,9 @@ def events_to_voxel_grid_batch(event_list, num_bins, width, height, normalize=Tr
     stats = torch.empty((B, 3), dtype=torch.float64, device=dev)
     L = _lib.load()
     with torch.cuda.device(dev):           # the stateless entry points launch on the CURRENT device
-        rc = L.cf_events_to_voxel(_lib.ptr(ev), _lib.ptr(offsets), B, num_bins, height, width, _lib.ptr(voxel), _lib.ptr(stats),
-                                  1 if normalize else 0, _lib.current_stream_ptr(dev))
+        rc = L.cf_events_to_voxel_ex(_lib.ptr(ev), _lib.ptr(offsets), B, num_bins, height, width, _lib.ptr(voxel), _lib.ptr(stats),
+                                     1 if normalize else 0, (25.0 / num_bins) if filter_hot_pixel else 0.0,
+                                     _lib.current_stream_ptr(dev))
     if rc != 0:
         raise RuntimeError("cf_events_to_voxel failed (%d)" % rc)
     return voxel

@@ -111,7 +111,8 @@ int cf_step(cf_handle* h, const float* in0, const float* in1, const float* rec_i
             const float* cc_prev, float* I_out, float* flow_final, float* flow_low, float* flow_preds,
             float* z_warped_out, float* c_out, float* z_out, float* h_out, float* cc_out, void* stream);
 
-/* hipGraph replay of cf_step (on by default; environment CF_GRAPH=0 turns it off).  A step is several hundred launches
+/* hipGraph replay of cf_step (opt-in: cf_graph_enable(h, 1) or environment CF_GRAPH=1; measured no faster than the eager
+ * launches on MI355X / ROCm 7.2 -- DESIGN.md section 8 -- so it is off by default).  A step is several hundred launches
  * over up to four streams; the library captures it once per distinct tuple of the 18 caller pointers (the second time
  * a tuple is seen) and replays the executable on a hit -- the same kernels with the same arguments, so results are
  * bit-identical to the eager path; callers whose buffers never repeat stay on the eager path.  Bypassed while
@@ -125,6 +126,12 @@ int cf_graph_stats(const cf_handle* h, long long* out3);
  * order; offsets: device int64 [B+1]; voxel: [B][bins][H][W] fp32; stats_scratch: 3*B doubles. */
 int cf_events_to_voxel(const double* events, const int64_t* offsets, int B, int bins, int H, int W, float* voxel,
                        double* stats_scratch, int normalize, void* stream);
+
+/* f-4: the voxel grids of the windows a reader cut out of an event stream
+ * (data_readers/video_readers.py:118-141, 211-232): as cf_events_to_voxel plus event_preprocess's hot-pixel filter --
+ * voxels with |v| > hot_pixel_threshold (the reference uses 25 / num_bins) are zeroed before the normalisation; <= 0: off. */
+int cf_events_to_voxel_ex(const double* events, const int64_t* offsets, int B, int bins, int H, int W, float* voxel,
+                          double* stats_scratch, int normalize, float hot_pixel_threshold, void* stream);
 
 /* f-2  output stage, `np.uint8(pred_image * 255.)` (test_with_flow.py:174): fp32 product, truncation toward zero,
  * on the device (img: n floats in [0,1], out: n bytes).  Stateless, asynchronous on `stream`.  The PNG encoder and the

@@ -571,9 +571,10 @@ def idnet_step(sd, batch_data, states, flow_init=None, warp_mode="forward", dept
 # ----------------------------------------------------------------------------------------------
 
 
-def events_to_voxel(events, num_bins, width, height, normalize=True):
+def events_to_voxel(events, num_bins, width, height, normalize=True, filter_hot_pixel=False):
     """events: numpy [N,4] float64 (t, x, y, polarity).  Temporal-bilinear accumulation then, if `normalize`,
-    the 'std' pre-processing: non-zero voxels to mean 0 / std 1, zeros stay zero."""
+    the 'std' pre-processing: non-zero voxels to mean 0 / std 1, zeros stay zero.  filter_hot_pixel: voxels with
+    |v| > 25 / num_bins are zeroed first (event_process.py:196-198)."""
     import numpy as np
     vox = np.zeros(num_bins * height * width, np.float32)
     if len(events):
@@ -593,6 +594,8 @@ def events_to_voxel(events, num_bins, width, height, normalize=True):
             if ti[k] + 1 < num_bins:
                 vox[xs[k] + ys[k] * width + (ti[k] + 1) * width * height] += pol[k] * dt[k]
     vox = vox.reshape(num_bins, height, width)
+    if filter_hot_pixel:
+        vox[np.abs(vox) > np.float32(25.0 / num_bins)] = 0
     if normalize:
         nz = vox != 0
         n = nz.sum()

@@ -24,3 +24,20 @@ def test_bench_two_rank_rehearsal(gpu):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
     assert out["value"] > 0 and out["roofline"] is not None and out["cpu_baseline"] is None
+
+
+def test_bench_single_rank_rccl_path(gpu):
+    """RCCL refuses two ranks on one device ("Duplicate GPU detected"), so the real backend can only be exercised here
+    with a world of one: CF_BENCH_FORCE_DIST=1 runs bench.py's whole N > 1 code path -- init_process_group("nccl",
+    device_id), all_gather_into_tensor of the reconstructed frames on the side stream with record_stream, the barriers
+    and the MAX all-reduce of the step time -- and checks that the gathered frames equal the local ones."""
+    env = dict(os.environ, CF_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29534")
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None), env.pop("LOCAL_RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", "2", "--height", "128",
+           "--width", "128", "--no-cpu-baseline", "--no-alt", "--no-roofline"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["value"] > 0

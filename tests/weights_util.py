@@ -85,3 +85,21 @@ def synth_events(B, bins, H, W, seed, density=0.13):
             m, s = v[b][nz].mean(), v[b][nz].std()
             out[b][nz] = (v[b][nz] - m) / (s if s > 0 else 1.0)
     return torch.from_numpy(out.astype(np.float32))
+
+
+def synth_event_file(path, seed=5, n=6000, width=36, height=28, duration=0.5, overshoot=True):
+    """A small whitespace-separated event file ('t x y pol', one header line) for the reader tests: sorted
+    timestamps, a few events beyond the sensor (x >= width / y >= height: the readers crop them) and one "hot" pixel
+    that fires every few events with the same polarity (|voxel| > 25 / bins: the hot-pixel filter zeroes it)."""
+    rng = np.random.default_rng([int(seed), 4242])
+    t = np.sort(rng.uniform(0.0, duration, n))
+    x = rng.integers(0, width + (3 if overshoot else 0), n)
+    y = rng.integers(0, height + (2 if overshoot else 0), n)
+    p = rng.integers(0, 2, n)
+    hot = np.arange(0, n, 9)
+    x[hot], y[hot], p[hot] = 7, 11, 1
+    with open(path, "w") as f:
+        f.write("%d %d\n" % (width, height))
+        for i in range(n):
+            f.write("%.9f %d %d %d\n" % (t[i], x[i], y[i], p[i]))
+    return np.stack([t, x, y, p], 1).astype(np.float64)

@@ -283,6 +283,84 @@ def run_metrics(name):
     print(name, {k: out[k] for k in ("mse", "psnr", "fwl")}, out["fm_valid_forward"], out["fm_photo_backward"])
 
 
+def run_readers(name):
+    """f-4: the reference's event readers and the event side of VR.update_event_frame_pack[_fix] on a
+    small synthetic event file (tests/weights_util.py::synth_event_file, regenerated by the tests from the seed)."""
+    import tempfile
+    import data_readers.event_readers as ref_er          # noqa: E402  (pandas is installed; cv2 is stubbed for video_readers)
+    import data_readers.video_readers as ref_vr          # noqa: E402
+    from weights_util import synth_event_file
+    W, H, bins = 36, 28, 5
+    d = tempfile.mkdtemp()
+    path = os.path.join(d, "events.txt")
+    synth_event_file(path, seed=5, n=6000, width=W, height=H, duration=0.5)
+    out = {"meta": np.array([5, 6000, W, H, bins], dtype=np.int64)}
+
+    def summary(ws):
+        return np.array([[len(w), w[0, 0] if len(w) else -1, w[-1, 0] if len(w) else -1, w[:, 1].sum() if len(w) else 0,
+                          w[:, 2].sum() if len(w) else 0, w[:, 3].sum() if len(w) else 0] for w in ws], dtype=np.float64)
+
+    def take(it, n):
+        ws = []
+        for _ in range(n):
+            try:
+                ws.append(np.asarray(next(it), dtype=np.float64))
+            except StopIteration:
+                break
+        return ws
+
+    out["fixed_700"] = summary(take(ref_er.FixedSizeEventReader(path, num_events=700), 8))
+    out["fixed_700_shift250"] = summary(take(ref_er.FixedSizeEventReader(path, num_events=700, k_shift=250), 12))
+    T = list(np.linspace(0.01, 0.49, 13))
+    # RefTimeEventReaderZip reads the file WITHOUT skipping a header: give it a header-less copy
+    path2 = os.path.join(d, "events_nohdr.txt")
+    with open(path) as f, open(path2, "w") as g:
+        g.writelines(f.readlines()[1:])
+    out["T_image"] = np.array(T)
+    out["reftime"] = summary(take(ref_er.RefTimeEventReaderZip(path2, T), 20))
+    # update_event_frame_pack does not crop to the sensor (the reference would index out of range): in-sensor events only
+    path3 = os.path.join(d, "events_in.txt")
+    synth_event_file(path3, seed=6, n=6000, width=W, height=H, duration=0.5, overshoot=False)
+    with open(path3) as f:
+        lines = f.readlines()[1:]
+    with open(path3, "w") as g:
+        g.writelines(lines)
+
+    class Fake(ref_vr.VR):
+        def start(self, reader, n):
+            self.r = iter(reader)
+            self.num_frames = n
+            self.frame_id = 0
+
+        def update_frame(self):
+            self.frame_id += 1
+            return np.full((self.height, self.width), self.frame_id % 250, np.uint8), 0
+
+        def update_events(self):
+            try:
+                return np.asarray(next(self.r), dtype=np.float64)
+            except StopIteration:
+                return None
+
+    for tag, method, mode, limit in (("fix_real", "update_event_frame_pack_fix", "real", 900),
+                                     ("fix_ups", "update_event_frame_pack_fix", "upsampled", 900),
+                                     ("pack_real", "update_event_frame_pack", "real", 300),
+                                     ("pack_plain", "update_event_frame_pack", "upsampled", -1)):
+        vr = Fake([H, W], num_bins=bins)
+        vr.start(ref_er.RefTimeEventReaderZip(path2 if tag.startswith("fix") else path3, T), len(T))
+        grids, nframes, nev, gts = [], [], [], []
+        for _ in range(40):
+            if vr.ending or vr.frame_id >= vr.num_frames:
+                break
+            ev, pack, gt = getattr(vr, method)(limit_num_events=limit, mode=mode)
+            grids += [np.asarray(e, dtype=np.float32) for e in ev]
+            nframes.append([len(ev), len(pack), vr.num_events, int(gt[0, 0])])
+        out[tag + "_grids"] = np.stack(grids)
+        out[tag + "_calls"] = np.array(nframes, dtype=np.int64)
+    np.savez_compressed(os.path.join(GOLD, name), **out)
+    print(name, {k: v.shape for k, v in out.items()})
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ref_model, ref_flow = import_reference()
@@ -302,6 +380,10 @@ def main():
     if "--only-new" in sys.argv:       # round 2 additions only (the round-1 fixtures stay byte-identical)
         run_metrics("metrics.npz")
         run_fullstate(ref_model, 100, 124, 2, 4, 21, "eiflow_100x124_fullstate.npz")
+        run_readers("readers.npz")
+        return
+    if "--only-readers" in sys.argv:
+        run_readers("readers.npz")
         return
     run_events("events.npz")
     run_idnet(ref_model, 68, 92, 2, 3, 41, "idnet_68x92.npz")
@@ -316,6 +398,7 @@ def main():
     run_eiflow(ref_model, 180, 240, 1, 2, 23, "forward", "eiflow_180x240.npz")
     run_metrics("metrics.npz")
     run_fullstate(ref_model, 100, 124, 2, 4, 21, "eiflow_100x124_fullstate.npz")
+    run_readers("readers.npz")
 
 
 if __name__ == "__main__":

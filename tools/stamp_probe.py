@@ -28,6 +28,9 @@ for case in CASES.split(","):
     torch.cuda.synchronize()
     d = buf.view(-1, 8).cpu()
     d = d[d[:, 4] > 0].double()
+    if r is None or d.shape[0] == 0:
+        print("%-34s tile %2d  no stamps (tile not available for this shape)" % (shape[0], int(tile)), flush=True)
+        continue
     n = d[:, 4].mean().item()
     m = d.mean(0)
     comp = (m[5] - m[0] - m[1] - m[2]) / n
