@@ -29,6 +29,13 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PEAK_F16_MFMA_TFLOPS = 2500.0   # same guide: dense f16 / bf16 MFMA (CF_PRECISION=f16; f16x3 spends 3 MFMAs per product)
+
+
+def mfma_peak():
+    """Dense MFMA peak for the arithmetic the convolutions run in (algorithmic flops are priced against it)."""
+    prec = os.environ.get("CF_PRECISION", "f32")
+    return {"f32": PEAK_FP32_MFMA_TFLOPS, "f16": PEAK_F16_MFMA_TFLOPS, "f16x3": PEAK_F16_MFMA_TFLOPS / 3.0}[prec]
 
 
 def parse():
@@ -141,7 +148,7 @@ def roofline_pass(model, step, B, dev, nprof):
         b_ms = sum(r["ms"] for r in rows if sel(r) and r["class"] == "hbm")
         b_w = sum(r["work"] for r in rows if sel(r) and r["class"] == "hbm")
         tot = m_ms + b_ms
-        mfr = (m_w / (m_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if m_ms else None
+        mfr = (m_w / (m_ms * 1e-3) / 1e12 / mfma_peak()) if m_ms else None
         hfr = (b_w / (b_ms * 1e-3) / 1e12 / PEAK_HBM_TBS) if b_ms else None
         comb = ((m_ms * (mfr or 0) + b_ms * (hfr or 0)) / tot) if tot else None
         return {"ms_per_step": round(tot / nprof, 3), "mfma_ms_per_step": round(m_ms / nprof, 3), "hbm_ms_per_step": round(b_ms / nprof, 3),
@@ -149,8 +156,8 @@ def roofline_pass(model, step, B, dev, nprof):
                 "time_weighted_frac": None if comb is None else round(comb, 4)}
 
     return {
-        "bound": "mfma", "kernel": dom_name, "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-        "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+        "bound": "mfma", "kernel": dom_name, "achieved": round(ach, 2), "peak": round(mfma_peak(), 1),
+        "unit": "TFLOP/s", "frac": round(ach / mfma_peak(), 4), "traffic": traffic,
         "note": "separate pass, HIP events on the launch stream, side streams folded into one stream (each kernel alone on the "
                 "chip), SAME launch grids as the timed step (half-batch CISTA chains kept, issued back to back)",
         "launches_per_step": dom["launches"] / nprof,
@@ -339,7 +346,8 @@ def main():
             "dtype": {"f32": "f32", "f16x3": "f16x3->f32acc", "f16": "f16->f32acc"}[os.environ.get("CF_PRECISION", "f32")],
             "data": "synthetic",
             "config": {"workload": "cista-%s %dx%d batch=%d sequences per GPU (BASELINE configs[%d]), flow iters %d, "
-                                   "CISTA depth 5, seeded random weights" % (a.model, H, W, B, {"eiflow": 1, "eraft": 2, "idnet": 4}[a.model],
+                                   "CISTA depth 5, seeded random weights" % (a.model, H, W, B,
+                                                                            {"eiflow": 3 if (H, W) == (480, 640) else 1, "eraft": 2, "idnet": 4}[a.model],
                                                                             model.flow_iters),
                        "sequences_per_gpu": B, "height": H, "width": W, "parallelism": "dp%d (independent sequences)" % world},
             "roofline": roofline, "cpu_baseline": cpu, "alt_precision": alt,

@@ -553,3 +553,21 @@ def test_graph_replay_is_bit_identical(gpu, kind):
         assert len(a) == len(b)
         for x, y in zip(a, b):
             assert torch.equal(x, y)
+
+
+def test_encoder_pair_mode_matches_two_stream_mode(gpu, monkeypatch):
+    """CF_ENC_PAIR=1 runs fnet + enet (eiflow) / fnet on both grids (eraft) as ONE batch of 2B images with grouped weights
+    instead of two chains on two streams: same layers and weights, tiles may differ (batch-dependent choice), so the
+    results agree to fp32 summation order; within a mode everything stays deterministic."""
+    H, W, B = 100, 124, 2
+    res = {}
+    for kind in ("eiflow", "eraft"):
+        for pair in ("0", "1"):
+            monkeypatch.setenv("CF_ENC_PAIR", pair)
+            m = _build(kind, H, W, 61, gpu)
+            evs = [wu.synth_events(B, 5, H, W, 800 + t).to(gpu) for t in range(3)]
+            with torch.no_grad():
+                res[(kind, pair)] = _drive(kind, m, evs[1:], evs[0], gpu)
+        for a, b in zip(res[(kind, "0")], res[(kind, "1")]):
+            for x, y in zip(a[:4], b[:4]):
+                assert gu.rel_err(x.cpu(), y.cpu()) < 2e-5, kind
