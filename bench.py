@@ -170,6 +170,9 @@ def roofline_pass(model, step, B, dev, nprof):
         # the HBM class: algorithmic bytes / HIP-event time against the 8 TB/s spec peak, per kernel and time-weighted
         "hbm": {"peak": PEAK_HBM_TBS, "unit": "TB/s", "achieved": round(hb_work / (hb_ms * 1e-3) / 1e12, 3) if hb_ms else None,
                 "frac": round(hb_work / (hb_ms * 1e-3) / 1e12 / PEAK_HBM_TBS, 4) if hb_ms else None,
+                # the same over the launches that move >= 8 MB (the others last 5-7 us whatever they move: launch-latency-bound)
+                "streaming_frac": (lambda big: round(sum(v["work"] for v in big) / (sum(v["ms"] for v in big) * 1e-3) / 1e12 / PEAK_HBM_TBS, 4)
+                                   if big else None)([r for r in rows if r["class"] == "hbm" and r["work"] / r["launches"] >= 8e6]),
                 "ms_per_step": round(hb_ms / nprof, 3), "launches_per_step": sum(v["launches"] for v in hb.values()) / nprof,
                 "by_kernel": {k: {"ms_per_step": round(v["ms"] / nprof, 4), "avg_launch_us": round(v["ms"] * 1e3 / v["launches"], 2),
                                   "mbytes_per_launch": round(v["work"] / v["launches"] / 1e6, 3),

@@ -55,8 +55,9 @@ struct Arena {
     bool measure = true;
     float* f(size_t nfloats) { return reinterpret_cast<float*>(raw(nfloats * sizeof(float))); }
     size_t skew = 0;          // CF_ARENA_SKEW (experiment): extra bytes between consecutive buffers
+    size_t align = 256;       // CF_ARENA_ALIGN (experiment): buffer alignment, power of two >= 256
     void* raw(size_t bytes) {
-        const size_t a = ((off + 255) & ~size_t(255)) + skew;
+        const size_t a = ((off + align - 1) & ~(align - 1)) + skew;
         off = a + bytes;
         if (measure) return reinterpret_cast<void*>(size_t(256));   // non-null placeholder
         return base + a;
@@ -816,6 +817,10 @@ extern "C" int cf_create(cf_handle** out, const cf_config* cfg) {
     }
     if (const char* e = getenv("CF_ENC_PAIR")) h->enc_pair = atoi(e) != 0;      // before the arena is laid out
     if (const char* e = getenv("CF_ARENA_SKEW")) h->arena.skew = (size_t)atol(e) & ~size_t(255);
+    if (const char* e = getenv("CF_ARENA_ALIGN")) {
+        const size_t a = (size_t)atol(e);
+        if (a >= 256 && (a & (a - 1)) == 0) h->arena.align = a;
+    }
     h->arena.measure = true;
     setup_buffers(h);
     const size_t bytes = h->arena.off + 256;
