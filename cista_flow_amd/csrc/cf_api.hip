@@ -40,6 +40,7 @@ struct RawWeight {
 
 struct PackedConv {
     float* w = nullptr;
+    float* wino = nullptr;   // Winograd F(2x2,3x3) transform of w (3x3 convs, fp32 mode; conv_wino_kernel)
     void* w16 = nullptr;     // f16 hi/lo split copy (precision != 0)
     float* bias = nullptr;
     int cout = 0, cin = 0, cin_pad = 0, KH = 0, KW = 0, Ktot = 0, rows = 0;
@@ -460,6 +461,7 @@ ConvParams nhwc_conv(const PackedConv& pc, std::initializer_list<Seg> segs, int 
     p.KH = pc.KH; p.KW = pc.KW; p.stride = stride; p.padT = padT; p.padL = padL; p.pad_mode = pad_mode;
     p.a_mode = A_NHWC;
     p.w = pc.w; p.w16 = pc.w16; p.w_bs = 0; p.w_rows = pc.rows; p.Ktot = pc.Ktot; p.cin_pad = pc.cin_pad; p.bias = pc.bias;
+    p.w_wino = pc.wino;
     if (pc.groups > 1) {     // images [g*batch/groups, (g+1)*batch/groups) use matrix g; run_conv turns w_div into images per group
         p.w_bs = (long)pc.rows * pc.Ktot;
         p.bias_gs = pc.rows;
@@ -755,6 +757,17 @@ extern "C" int cf_finalize_weights(cf_handle* h, void* stream) {
             if (h->conv["idn.gru.q"].cin != 160 || h->conv["idn.mask.2"].cout != 576)
                 return h->fail(CF_ERR_WEIGHT, "IDNet weights do not match hidden_dim=96 / downsample=8");
             h->has_flow = true;
+        }
+    }
+    if (h->cfg.precision == 0) {
+        // fp32: every plain 3x3 matrix also gets its Winograd transform U = G g G^T (16/9 of its size), made from the
+        // PACKED matrix so that BatchNorm folds, row stacking / interleaving and channel slices carry over
+        for (auto& kv : h->conv) {
+            PackedConv& pc = kv.second;
+            if (!pc.w || pc.gather || pc.KH != 3 || pc.KW != 3 || pc.groups != 1) continue;
+            CF_HIP(h, hipMalloc(reinterpret_cast<void**>(&pc.wino), sizeof(float) * (size_t)wino_weight_floats(pc.cout, pc.cin_pad)));
+            h->owned.push_back(pc.wino);
+            CF_HIP(h, launch_wino_weights(pc.w, pc.wino, pc.cout, pc.cin_pad, st));
         }
     }
     if (h->cfg.precision != 0) {
@@ -1880,6 +1893,12 @@ static int op_conv2d_impl(const float* in, int B, int Cin, int H, int W, const f
         if (launch_split_weight_f16(pc.w, w16.p, pc.rows, pc.Ktot, st) != hipSuccess) return CF_ERR_HIP;
         p.w16 = w16.p;
         p.prec = prec;
+    }
+    TmpBuf wino;
+    if (tile == 40 && !gather && KH == 3 && KW == 3) {      // Winograd tile: needs the transformed weights
+        if (hipMalloc(&wino.p, sizeof(float) * (size_t)wino_weight_floats(Cout, pc.cin_pad)) != hipSuccess) return CF_ERR_HIP;
+        if (launch_wino_weights(pc.w, static_cast<float*>(wino.p), Cout, pc.cin_pad, st) != hipSuccess) return CF_ERR_HIP;
+        p.w_wino = static_cast<float*>(wino.p);
     }
     TmpBuf part;
     if (stats_out) {   // fused InstanceNorm statistics

@@ -259,9 +259,11 @@ __device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned of
 
 // it0 / it1: which of the lane's four quads (pixel rows (lane >> 3) + 8 it) to finish; nparts / pstride: the patch is the
 // sum of nparts partial patches pstride floats apart (split-K tiles: every wave finishes its share of the rows).
+// mtab (nullable, LDS): row r of the patch is output pixel mtab[r] (< 0: no pixel) instead of mrow0 + r -- tiles whose rows
+// are not consecutive pixels (the Winograd kernel's 2x2 output blocks)
 template <int EB, int CLS>
 __device__ __forceinline__ void patch_tail_fast(const ConvParams& p, const float* sW, int b, int mrow0, int nbase, int lane,
-                                                int M, int it0, int it1, int nparts, int pstride) {
+                                                int M, int it0, int it1, int nparts, int pstride, const int* mtab = nullptr) {
     const int n = nbase + (lane & 7) * 4;
     const int mb = mrow0 + (lane >> 3);
     const int epi = p.epi;
@@ -286,8 +288,8 @@ __device__ __forceinline__ void patch_tail_fast(const ConvParams& p, const float
         EpiAux x[EB];
 #pragma unroll
         for (int it = 0; it < EB; ++it) {
-            const int m = mb + (h + it) * 8;
-            const bool ok = m < M && h + it < it1;
+            const int m = mtab ? mtab[((lane >> 3) + (h + it) * 8) & 31] : mb + (h + it) * 8;
+            const bool ok = (mtab ? m >= 0 : m < M) && h + it < it1;
             const unsigned um = (unsigned)m;
             const unsigned o0 = ok ? um * (4u * (unsigned)p.aux0_ld) + n4 : BUF_OOB;
             if constexpr (CLS == 1) {
@@ -315,8 +317,8 @@ __device__ __forceinline__ void patch_tail_fast(const ConvParams& p, const float
         }
 #pragma unroll
         for (int it = 0; it < EB; ++it) {
-            const int m = mb + (h + it) * 8;
-            const bool ok = m < M && h + it < it1;
+            const int m = mtab ? mtab[((lane >> 3) + (h + it) * 8) & 31] : mb + (h + it) * 8;
+            const bool ok = (mtab ? m >= 0 : m < M) && h + it < it1;
             const unsigned um = (unsigned)m;
             const int srow = ((lane >> 3) + ((h + it) & 3) * 8) * EPI_S + (lane & 7) * 4;
             f32x4 acc = *reinterpret_cast<const f32x4*>(sW + srow);
@@ -458,22 +460,22 @@ __device__ __forceinline__ void patch_tail_fast(const ConvParams& p, const float
 
 // generic tail: any alignment, partial quads, strided outputs (out_cs != 1), EPI_ADD_AUX
 __device__ __forceinline__ void patch_tail(const ConvParams& p, const float* sW, int b, int mrow0, int nbase, int lane, int M,
-                                           int it0 = 0, int it1 = 4, int nparts = 1, int pstride = 0) {
+                                           int it0 = 0, int it1 = 4, int nparts = 1, int pstride = 0, const int* mtab = nullptr) {
     if (p.epi_vec && nbase + 32 <= p.cout) {      // wave-uniform
         const int epi = p.epi;
         const bool one_aux = epi == EPI_SUB_FROM_AUX || epi == EPI_ADD_AUX_SHRINK || epi == EPI_RELU_ADD_AUX ||
                              epi == EPI_RELU_ADD_AUX_RELU || epi == EPI_LSTM_CELL;
-        if (epi == EPI_LSTC) patch_tail_fast<1, 3>(p, sW, b, mrow0, nbase, lane, M, it0, it1, nparts, pstride);
-        else if (p.addend || epi == EPI_GRU_ZR || epi == EPI_GRU_Q) patch_tail_fast<2, 2>(p, sW, b, mrow0, nbase, lane, M, it0, it1, nparts, pstride);
-        else if (one_aux) patch_tail_fast<4, 1>(p, sW, b, mrow0, nbase, lane, M, it0, it1, nparts, pstride);
-        else patch_tail_fast<4, 0>(p, sW, b, mrow0, nbase, lane, M, it0, it1, nparts, pstride);
+        if (epi == EPI_LSTC) patch_tail_fast<1, 3>(p, sW, b, mrow0, nbase, lane, M, it0, it1, nparts, pstride, mtab);
+        else if (p.addend || epi == EPI_GRU_ZR || epi == EPI_GRU_Q) patch_tail_fast<2, 2>(p, sW, b, mrow0, nbase, lane, M, it0, it1, nparts, pstride, mtab);
+        else if (one_aux) patch_tail_fast<4, 1>(p, sW, b, mrow0, nbase, lane, M, it0, it1, nparts, pstride, mtab);
+        else patch_tail_fast<4, 0>(p, sW, b, mrow0, nbase, lane, M, it0, it1, nparts, pstride, mtab);
         return;
     }
     const int nb = nbase + (lane & 7) * 4;
     const int mb = mrow0 + (lane >> 3);
 #pragma unroll 1
     for (int it = it0; it < it1; ++it) {
-        const int m = mb + it * 8;
+        const int m = mtab ? mtab[((lane >> 3) + it * 8) & 31] : mb + it * 8;
         const int srow = ((lane >> 3) + it * 8) * EPI_S + (lane & 7) * 4;
         f32x4 v = *reinterpret_cast<const f32x4*>(sW + srow);
         for (int k = 1; k < nparts; ++k) {
@@ -481,7 +483,7 @@ __device__ __forceinline__ void patch_tail(const ConvParams& p, const float* sW,
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += t[e];
         }
-        if (m < M && nb < p.cout) epilogue4(p, b, m, nb, v);
+        if ((mtab ? m >= 0 : m < M) && nb < p.cout) epilogue4(p, b, m, nb, v);
     }
 }
 
@@ -1409,6 +1411,265 @@ void conv_dma_kernel(const ConvParams p) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Winograd F(2x2, 3x3) for the 3x3 / stride 1 / pad 1 convolutions (reflect or zero pad), fp32:
+//     Y = A^T [ sum_c (G g G^T) .* (B^T d B) ] A          per 4x4 input tile d -> 2x2 output tile,
+// i.e. 16 independent [tiles x Cin] x [Cin x Cout] products instead of 9 taps: 2.25x fewer matrix-core flops, the same
+// fp32 products and accumulation (results differ from the direct kernel by the transforms' rounding, ~1e-6).
+// The un-fused form (transform kernels + batched GEMM) moves 4x the input and 4x the output through memory and loses
+// on this machine, so everything is fused in one workgroup (256 threads) per region of 4 x 8 tiles (8 x 16 output
+// pixels) x 32 output channels, K = Cin in chunks of 8 channels:
+//   raw     the (10 x 18 pixel) x 8-channel input patch of a chunk, LDS-DMA'd straight from the NHWC tensor (reflect /
+//           zero padding resolved in the per-lane source offset; double buffered);
+//   V       = B^T d B for the 32 tiles, one (tile, channel) pair per thread (32 adds), written [pos][tile][8 k];
+//   U       = G g G^T, transformed ONCE at weight-pack time into [n-block][chunk][pos][32 n][8 k] blocks, so a chunk's
+//           16 KB arrive by linear LDS-DMA (double buffered);
+//   MFMA    wave w owns positions (w, 0..3) of the 4x4 grid: 4 accumulators [32 tiles x 32 couts], 16 x
+//           v_mfma_f32_32x32x2_f32 per chunk; the 16-byte fragment slots of V / U rows are XOR-swizzled by (row >> 3) & 1
+//           so that ds_read_b128 is conflict free;
+//   tail    the A^T . A reduction is separable: along j inside the wave (registers), along i across the four waves
+//           through LDS; each wave then owns one tile row = 32 output pixels x 32 couts as a patch and runs the
+//           common fused epilogue (patch_tail) with a row -> pixel table.
+// Two workgroups per CU (78 KB LDS each): one transforms while the other multiplies.
+// ---------------------------------------------------------------------------------------------------------
+static constexpr int WG_TH = 4, WG_TW = 8;                  // tiles per region
+static constexpr int WG_PR = 2 * WG_TH + 2, WG_PC = 2 * WG_TW + 2, WG_PIX = WG_PR * WG_PC;   // 10 x 18 = 180 patch pixels
+static constexpr int WG_KC = 8;                             // channels per chunk
+static constexpr int WG_RAW = 384 * 4;                      // floats per raw buffer: 360 16-byte slots, padded to whole wave-instructions
+static constexpr int WG_UV = 16 * 32 * WG_KC;               // floats per U / V buffer (4096)
+
+__global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParams p) {
+    __shared__ __attribute__((aligned(16))) float sV[WG_UV];
+    __shared__ __attribute__((aligned(16))) float sU[2 * WG_UV];            // reused as the cross-wave exchange X[4][2][32][32]
+    __shared__ __attribute__((aligned(16))) float sRaw[2 * WG_RAW];
+    __shared__ __attribute__((aligned(16))) float sPatch[4 * 32 * EPI_S];
+    __shared__ int sMtab[4 * 32];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Ho = p.Ho, Wo = p.Wo;
+    const int nrx = (Wo + 2 * WG_TW - 1) / (2 * WG_TW), nry = (Ho + 2 * WG_TH - 1) / (2 * WG_TH);
+    const int nreg = nrx * nry;
+    const int nt = (p.cout + 31) / 32;
+    int tile_id = blockIdx.x;
+    if (p.sched == 1) {
+        const int nwg = gridDim.x;
+        const int q8 = nwg >> 3, r8 = nwg & 7;
+        const int xcd = tile_id & 7;
+        tile_id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (tile_id >> 3);
+    }
+    const int nblk = tile_id % nt;
+    const int rest = tile_id / nt;
+    const int reg = rest % nreg;
+    const int b = rest / nreg;
+    const int oy0 = (reg / nrx) * (2 * WG_TH), ox0 = (reg % nrx) * (2 * WG_TW);
+    const int n0 = nblk * 32;
+
+    // ---- raw patch DMA slots: slot s -> patch pixel s >> 1, channel quad s & 1 ----
+    int a_pix[2];
+    unsigned a_q[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int sl = tid + 256 * j;
+        const int pix = sl >> 1;
+        a_q[j] = (unsigned)(sl & 1) * 16u;
+        const int py = pix / WG_PC, px = pix - py * WG_PC;
+        int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+        bool ok = sl < 2 * WG_PIX && iy <= p.Hin && ix <= p.Win;      // beyond the halo of the last row / column: unused
+        if (p.pad_mode == 1) {
+            iy = reflect_idx(iy, p.Hin);
+            ix = reflect_idx(ix, p.Win);
+        } else {
+            ok = ok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+        }
+        a_pix[j] = ok ? iy * p.Win + ix : -1;
+    }
+    const int nchunk = p.cin_pad / WG_KC;
+    const __amdgpu_buffer_rsrc_t u_rsrc = make_rsrc(p.w_wino + (long)nblk * nchunk * WG_UV);
+
+    // chunk iterator over the channel segments (wave-uniform)
+    int it_seg = 0, it_cs = 0;
+    const float* seg_base = p.in[0] + (long)b * p.seg_bs[0];
+    int seg_ld = p.seg_ld[0], seg_cn = p.seg_c[0];
+    auto issue = [&](int chunk, int buf) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(seg_base);
+        const unsigned ld4 = (unsigned)seg_ld * 4u, so = (unsigned)it_cs * 4u;
+        float* rbase = sRaw + buf * WG_RAW;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (256 * j + 64 * wave < 2 * WG_PIX) {        // wave-uniform: this wave-instruction covers live slots
+                const unsigned off = a_pix[j] < 0 ? BUF_OOB : (unsigned)a_pix[j] * ld4 + a_q[j];
+                dma16_to_lds(rs, rbase + (256 * j + 64 * wave) * 4, off, so);
+            }
+        }
+        float* ubase = sU + buf * WG_UV;
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+            dma16_to_lds(u_rsrc, ubase + (256 * it + 64 * wave) * 4, (unsigned)(tid + 256 * it) * 16u, (unsigned)chunk * (WG_UV * 4u));
+        // advance to the next chunk
+        it_cs += WG_KC;
+        if (it_cs >= seg_cn) {
+            it_cs = 0;
+            ++it_seg;
+            if (it_seg < p.nseg) {
+                seg_base = sel3(p.in, it_seg) + (long)b * (it_seg == 1 ? p.seg_bs[1] : p.seg_bs[2]);
+                seg_ld = it_seg == 1 ? p.seg_ld[1] : p.seg_ld[2];
+                seg_cn = it_seg == 1 ? p.seg_c[1] : p.seg_c[2];
+            }
+        }
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    // transform mapping: tile (row = wave, column = lane >> 3), channel lane & 7
+    const int tcol = lane >> 3, tc = lane & 7;
+    const int rsrc0 = (2 * wave * WG_PC + 2 * tcol) * WG_KC + tc;                       // patch pixel (2 ty, 2 tx), channel tc
+    const int vdst = ((wave * 8 + tcol) * WG_KC) + ((((tc >> 2) ^ (wave & 1)) << 2) | (tc & 3));   // + pos * 32 * 8
+    // fragment addresses (floats): row lr of position (wave, j), k quad lh (swizzled by (lr >> 3) & 1)
+    const int lr = lane & 31, lh = lane >> 5;
+    const int frag = lr * WG_KC + ((lh ^ ((lr >> 3) & 1)) << 2);
+
+    issue(0, 0);
+    for (int k = 0; k < nchunk; ++k) {
+        wait_vmcnt0();
+        raw_barrier();                              // chunk k has landed for everybody; iteration k-1 is finished everywhere
+        if (k + 1 < nchunk) issue(k + 1, (k + 1) & 1);
+        // ---- input transform V = B^T d B ----
+        {
+            const float* r = sRaw + (k & 1) * WG_RAW + rsrc0;
+            float d[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[i][j] = r[(i * WG_PC + j) * WG_KC];
+            float t[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                t[0][j] = d[0][j] - d[2][j];
+                t[1][j] = d[1][j] + d[2][j];
+                t[2][j] = d[2][j] - d[1][j];
+                t[3][j] = d[1][j] - d[3][j];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sV[(i * 4 + 0) * 256 + vdst] = t[i][0] - t[i][2];
+                sV[(i * 4 + 1) * 256 + vdst] = t[i][1] + t[i][2];
+                sV[(i * 4 + 2) * 256 + vdst] = t[i][2] - t[i][1];
+                sV[(i * 4 + 3) * 256 + vdst] = t[i][1] - t[i][3];
+            }
+        }
+        wait_lgkm0();                               // this wave's V writes are done ...
+        raw_barrier();                              // ... and everybody's (NOT __syncthreads: it would drain the DMA of chunk k+1)
+        // ---- 16 MFMAs: positions (wave, 0..3) ----
+        {
+            const float* ub = sU + (k & 1) * WG_UV;
+            f32x4 af[4], bf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                af[j] = *reinterpret_cast<const f32x4*>(sV + (wave * 4 + j) * 256 + frag);
+                bf[j] = *reinterpret_cast<const f32x4*>(ub + (wave * 4 + j) * 256 + frag);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][s2], bf[j][s2], acc[j], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                // every wave is done with U before it becomes the exchange buffer
+    // ---- output transform, j direction (in registers): R[0] = M0 + M1 + M2, R[1] = M1 - M2 - M3 ----
+    float* X = sU;                                  // X[i = wave][bcol][tile 32][cout 32]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int trow = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        X[((wave * 2 + 0) * 32 + trow) * 32 + lr] = (acc[0][r] + acc[1][r]) + acc[2][r];
+        X[((wave * 2 + 1) * 32 + trow) * 32 + lr] = (acc[1][r] - acc[2][r]) - acc[3][r];
+    }
+    __syncthreads();
+    // ---- i direction across the waves + patch of this wave's tile row: 8 tiles x (2 x 2) pixels x 32 couts ----
+    float* sW = sPatch + wave * (32 * EPI_S);
+    int* mtab = sMtab + wave * 32;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int prow = lh * 16 + q;               // patch row = tl * 4 + a * 2 + bb
+        const int tl = prow >> 2, a = (prow >> 1) & 1, bb = prow & 1;
+        const int t = wave * 8 + tl;
+        const float x0 = X[((0 * 2 + bb) * 32 + t) * 32 + lr], x1 = X[((1 * 2 + bb) * 32 + t) * 32 + lr];
+        const float x2 = X[((2 * 2 + bb) * 32 + t) * 32 + lr], x3 = X[((3 * 2 + bb) * 32 + t) * 32 + lr];
+        sW[prow * EPI_S + lr] = a == 0 ? (x0 + x1) + x2 : (x1 - x2) - x3;
+    }
+    if (lane < 32) {
+        const int tl = lane >> 2, a = (lane >> 1) & 1, bb = lane & 1;
+        const int oy = oy0 + 2 * wave + a, ox = ox0 + 2 * tl + bb;
+        mtab[lane] = (oy < Ho && ox < Wo) ? oy * Wo + ox : -1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    patch_tail(p, sW, b, 0, n0, lane, Ho * Wo, 0, 4, 1, 0, mtab);
+}
+
+// U = G g G^T of a packed direct matrix w [rows][tap][cin_pad] (BatchNorm folds, stacking, interleaving already applied),
+// stored [n-block][chunk][pos = i*4+j][32 n][8 k] with the 16-byte k quads of a row swapped for rows 8..15 and 24..31
+// (the swizzle conv_wino_kernel reads with); rows past `rows` are zero
+__global__ void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ u, int rows, int cin_pad, int nblk) {
+    const int nchunk = cin_pad / WG_KC;
+    const long total = (long)nblk * nchunk * WG_UV;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int kk = (int)(idx & 7);
+    const int nl = (int)((idx >> 3) & 31);
+    const int pos = (int)((idx >> 8) & 15);
+    const long blk = idx >> 12;
+    const int chunk = (int)(blk % nchunk);
+    const int nb = (int)(blk / nchunk);
+    const int n = nb * 32 + nl;
+    const int kq = (kk >> 2) ^ ((nl >> 3) & 1);                 // un-swizzle: which logical k this slot holds
+    const int c = chunk * WG_KC + kq * 4 + (kk & 3);
+    float val = 0.f;
+    if (n < rows) {
+        const float G[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
+        const int i = pos >> 2, j = pos & 3;
+        double acc = 0.0;
+        for (int a = 0; a < 3; ++a)
+            for (int bq = 0; bq < 3; ++bq)
+                acc += (double)G[i][a] * (double)w[(long)n * 9 * cin_pad + (long)(a * 3 + bq) * cin_pad + c] * (double)G[j][bq];
+        val = (float)acc;
+    }
+    u[idx] = val;
+}
+
+hipError_t launch_wino_weights(const float* w, float* u, int rows, int cin_pad, hipStream_t s) {
+    if (!w || !u || rows <= 0 || cin_pad <= 0 || (cin_pad % WG_KC) != 0) return hipErrorInvalidValue;
+    const int nblk = (rows + 31) / 32;
+    const long total = (long)nblk * (cin_pad / WG_KC) * WG_UV;
+    hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, u, rows, cin_pad, nblk);
+    return hipGetLastError();
+}
+long wino_weight_floats(int rows, int cin_pad) { return (long)((rows + 31) / 32) * (cin_pad / WG_KC) * WG_UV; }
+
+static bool wino_ok(const ConvParams& p) {
+    if (p.a_mode != A_NHWC || p.prec != 0 || !p.w_wino || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.padT != 1 || p.padL != 1) return false;
+    if (p.Ho != p.Hin || p.Wo != p.Win || p.Hin < 12 || p.Win < 12 || p.st_partial || p.w_bs != 0 || p.bias_gs != 0) return false;
+    for (int i = 0; i < p.nseg; ++i)
+        if (p.seg_c[i] % WG_KC) return false;
+    return true;
+}
+
+static hipError_t launch_wino(const ConvParams& p, int batch, hipStream_t s) {
+    if (!wino_ok(p)) return hipErrorInvalidValue;
+    const long nreg = (long)((p.Wo + 2 * WG_TW - 1) / (2 * WG_TW)) * ((p.Ho + 2 * WG_TH - 1) / (2 * WG_TH));
+    const long wgs = nreg * ((p.cout + 31) / 32) * batch;
+    if (wgs <= 0 || wgs >= 0x7FFFFFFFL) return hipErrorInvalidValue;
+    g_last_launch.threads = wgs * 256;
+    hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)wgs), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
 template <int BM, int BN, int WM, int WN, int WK, int KCW, int NBUF = 3>
 static hipError_t launch_dma(const ConvParams& p, int batch, hipStream_t s) {
     if (p.a_mode != A_NHWC || p.prec != 0 || !stage_ok(p, KCW * WK)) return hipErrorInvalidValue;
@@ -1651,6 +1912,7 @@ const char* conv_tile_name(int tile) {
         case 32: return "conv_dma_kernel<64,64,2,2,1,16,nbuf4>";
         case 33: return "conv_dma_kernel<128,64,2,2,1,16,nbuf4>";
         case 34: return "conv_dma_kernel<32,96,1,1,4,8>";
+        case 40: return "conv_wino_kernel";
         default: return "?";
     }
 }
@@ -1660,6 +1922,15 @@ static int default_sched() {
     if (v < 0) {
         const char* e = getenv("CF_SCHED");
         v = e ? atoi(e) : 1;
+    }
+    return v;
+}
+
+static int default_wino() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("CF_WINO");
+        v = e ? atoi(e) : 0;
     }
     return v;
 }
@@ -1736,6 +2007,7 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
         if (tile_used) *tile_used = 7;
         return launch_smalln(p, batch, s, tile == 15);
     }
+    if (tile == 0 && default_wino() && wino_ok(p)) tile = 40;
     if (tile == 0) {
         // Pick the largest tile that still yields >= ~2 workgroups per CU (measured with tools/conv_bench.py on
         // MI355X): big tiles reuse operands best, but a launch with fewer than ~512 workgroups leaves CUs idle,
@@ -1827,6 +2099,7 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
         case 32: return launch_dma<64, 64, 2, 2, 1, 16, 4>(p, batch, s);
         case 33: return launch_dma<128, 64, 2, 2, 1, 16, 4>(p, batch, s);
         case 34: return launch_dma<32, 96, 1, 1, 4, 8>(p, batch, s);
+        case 40: return launch_wino(p, batch, s);
         default: return hipErrorInvalidValue;
     }
 }

@@ -188,6 +188,30 @@ def test_conv_nhwc(gpu, case):
     assert err < 1e-4, err
 
 
+WINO_CASES = [(64, 64, 1, 20, 28, 0), (128, 64, 0, 20, 28, 1), (16, 32, 1, 13, 21, 2), (48, 96, 0, 24, 40, 3),
+              (256, 126, 0, 24, 32, 1), (192, 256, 1, 17, 33, 0), (64, 128, 1, 90, 120, 0)]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_conv_winograd(gpu, case):
+    """conv_wino_kernel (tile 40): Winograd F(2x2,3x3) for 3x3 / stride 1 / pad 1, reflect and zero padding, partial
+    regions (sizes that are not multiples of 8 x 16), a cout that is not a multiple of 32 and the fused activations --
+    against F.conv2d, and against the direct kernel to ~1e-6 of tensor scale (the transforms' rounding)."""
+    Cin, Cout, pad_mode, H, W, epi = case
+    g = torch.Generator().manual_seed(1000 + Cin + Cout + H)
+    B = 2
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = ref_conv(x, w, b, 1, 1, 1, pad_mode)
+    ref = {0: lambda t: t, 1: torch.relu, 2: torch.sigmoid, 3: torch.tanh}[epi](ref)
+    got = run_conv(gpu, x, w, b, 1, 1, 1, pad_mode, 0, epi, 40, H, W)
+    direct = run_conv(gpu, x, w, b, 1, 1, 1, pad_mode, 0, epi, 0, H, W)
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() < 1e-4
+    assert (got - direct).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("epi", [1, 2, 3])
 def test_conv_epilogue_activation(gpu, epi):
     g = torch.Generator().manual_seed(7 + epi)
