@@ -130,6 +130,7 @@ struct cf_handle {
     int win_b0 = 0, win_n = 0;
     int enc_tile_batch = 0;        // tile-choice batch of the encoder being issued (ConvParams::tile_batch)
     int enc_group_sel = -1;        // >= 0: the encoder being issued uses this matrix of its grouped PackedConvs
+    int last_tile = 0;             // tile kind of the last run_conv launch (statistics chunk count of the Winograd tile)
     bool enc_pair = false;         // CF_ENC_PAIR=1: fnet + enet as one 2B batch instead of two streams
     // CF_PHASES=1 (tuning aid): HIP events on the caller's stream at the phase boundaries of cf_step, averaged
     // and printed to stderr by cf_destroy
@@ -244,13 +245,15 @@ static hipError_t run_conv(cf_handle* h, const ConvParams& p_in, int batch, hipS
         p.w += (long)h->enc_group_sel * p.w_bs;
         if (p.w16) p.w16 = static_cast<const char*>(p.w16) + (long)h->enc_group_sel * p.w_bs * 4;
         if (p.bias) p.bias += (long)h->enc_group_sel * p.bias_gs;
-        p.w_bs = 0; p.bias_gs = 0; p.w_div = 0;
+        if (p.w_wino) p.w_wino += (long)h->enc_group_sel * p.wino_gs;
+        p.w_bs = 0; p.bias_gs = 0; p.w_div = 0; p.wino_gs = 0;
     }
     if (p.w_div < 0) {
         if (batch % (-p.w_div) != 0) return hipErrorInvalidValue;
         p.w_div = batch / (-p.w_div);
     }
-    if (!h || !h->prof) return launch_conv(p, batch, st, tile);
+    if (!h) return launch_conv(p, batch, st, tile);
+    if (!h->prof) return launch_conv(p, batch, st, tile, &h->last_tile);
     cf_handle::ProfRec r;
     r.a = h->prof_event();
     r.b = h->prof_event();
@@ -260,6 +263,7 @@ static hipError_t run_conv(cf_handle* h, const ConvParams& p_in, int batch, hipS
     r.tag = p.tag ? p.tag : h->tag;
     (void)hipEventRecord(r.a, st);
     hipError_t e = launch_conv(p, batch, st, tile, &r.tile);
+    h->last_tile = r.tile;
     (void)hipEventRecord(r.b, st);
     if (r.tile == 7) {      // 1-2 output channels on the vector ALUs: reads the input once, HBM class
         r.cls = 1;
@@ -466,6 +470,7 @@ ConvParams nhwc_conv(const PackedConv& pc, std::initializer_list<Seg> segs, int 
         p.w_bs = (long)pc.rows * pc.Ktot;
         p.bias_gs = pc.rows;
         p.w_div = -pc.groups;
+        p.wino_gs = pc.wino ? wino_weight_floats(pc.cout, pc.cin_pad) : 0;
     }
     p.out = out; p.out_ld = out_ld; p.out_bs = out_bs; p.cout = pc.cout; p.epi = epi;
     p.k_real = pc.cin * pc.KH * pc.KW;
@@ -764,10 +769,12 @@ extern "C" int cf_finalize_weights(cf_handle* h, void* stream) {
         // PACKED matrix so that BatchNorm folds, row stacking / interleaving and channel slices carry over
         for (auto& kv : h->conv) {
             PackedConv& pc = kv.second;
-            if (!pc.w || pc.gather || pc.KH != 3 || pc.KW != 3 || pc.groups != 1) continue;
-            CF_HIP(h, hipMalloc(reinterpret_cast<void**>(&pc.wino), sizeof(float) * (size_t)wino_weight_floats(pc.cout, pc.cin_pad)));
+            if (!pc.w || pc.gather || pc.KH != 3 || pc.KW != 3) continue;
+            const size_t wf = (size_t)wino_weight_floats(pc.cout, pc.cin_pad);
+            CF_HIP(h, hipMalloc(reinterpret_cast<void**>(&pc.wino), sizeof(float) * wf * pc.groups));
             h->owned.push_back(pc.wino);
-            CF_HIP(h, launch_wino_weights(pc.w, pc.wino, pc.cout, pc.cin_pad, st));
+            for (int g = 0; g < pc.groups; ++g)
+                CF_HIP(h, launch_wino_weights(pc.w + (size_t)g * pc.rows * pc.Ktot, pc.wino + g * wf, pc.cout, pc.cin_pad, st));
         }
     }
     if (h->cfg.precision != 0) {
@@ -1205,7 +1212,7 @@ static int encoder_forward(cf_handle* h, const std::string& pre, bool bn, const 
             ConvParams p = gather_conv(h->conv[ins[g].conv1_key + ".conv1"], ins[g].in, ins[g].Cin, h->H, h->W, h->padH, h->padW,
                                        ins[g].scale, ins[g].shift, 0, Hc, Wc, 2, 3, 3, 0, (bn ? A : Bf) + (long)g * B * obs, 64, obs,
                                        bn ? EPI_RELU : EPI_NONE);
-            if (!bn) p.st_partial = sc.partial + (long)g * B * npatch * 64 * 2;      // InstanceNorm statistics ride on the conv epilogue
+            if (!bn) p.st_partial = sc.partial + (long)g * B * npatch * 64 * 2;      // InstanceNorm statistics ride on the conv epilogue (gather conv: 32-pixel patches)
             CF_HIP(h, run_conv(h, p, B, st));
         }
         if (!bn) {
@@ -1241,15 +1248,17 @@ static int encoder_forward(cf_handle* h, const std::string& pre, bool bn, const 
                 CF_HIP(h, run_conv(h, c2, BB, st));
                 std::swap(A, Df);
             } else {
-                const int nch = (Ho * Wo + 31) / 32;
+                int nch = (Ho * Wo + 31) / 32;
                 ConvParams c1 = nhwc_conv(K(b + ".conv1"), {{A, Cx, Cx, ibs}}, Hc, Wc, Ho, Wo, stride, 1, 1, 0, Bf, Cd, obs, EPI_NONE);
                 c1.st_partial = sc.partial;
                 CF_HIP(h, run_conv(h, c1, BB, st));
+                nch = conv_stats_chunks(c1, h->last_tile);
                 { PROF(h, st, "enc.inorm_final", 16.0 * BB * nch * Cd); CF_HIP(h, launch_inorm_final(sc.partial, nch, BB, Ho * Wo, Cd, eps, sc.stats, st)); }
                 { PROF(h, st, "enc.inorm_apply", 8.0 * BB * Ho * Wo * Cd); CF_HIP(h, launch_inorm_apply(Bf, Cd, obs, sc.stats, nullptr, 0, 0, nullptr, Cf, Cd, obs, BB, Ho * Wo, Cd, st)); }
                 ConvParams c2 = nhwc_conv(K(b + ".conv2"), {{Cf, Cd, Cd, obs}}, Ho, Wo, Ho, Wo, 1, 1, 1, 0, Bf, Cd, obs, EPI_NONE);
                 c2.st_partial = sc.partial;
                 CF_HIP(h, run_conv(h, c2, BB, st));
+                nch = conv_stats_chunks(c2, h->last_tile);
                 { PROF(h, st, "enc.inorm_final", 16.0 * BB * nch * Cd); CF_HIP(h, launch_inorm_final(sc.partial, nch, BB, Ho * Wo, Cd, eps, sc.stats, st)); }
                 const float* res = A;
                 int res_ld = Cx;
@@ -1259,6 +1268,7 @@ static int encoder_forward(cf_handle* h, const std::string& pre, bool bn, const 
                     ConvParams ds = nhwc_conv(K(b + ".downsample.0"), {{A, Cx, Cx, ibs}}, Hc, Wc, Ho, Wo, stride, 0, 0, 0, Cf, Cd, obs, EPI_NONE);
                     ds.st_partial = sc.partial;
                     CF_HIP(h, run_conv(h, ds, BB, st));
+                    nch = conv_stats_chunks(ds, h->last_tile);
                     { PROF(h, st, "enc.inorm_final", 16.0 * BB * nch * Cd); CF_HIP(h, launch_inorm_final(sc.partial, nch, BB, Ho * Wo, Cd, eps, sc.stats2, st)); }
                     res = Cf; res_ld = Cd; res_bs = obs; res_stats = sc.stats2;
                 }
@@ -1905,9 +1915,10 @@ static int op_conv2d_impl(const float* in, int B, int Cin, int H, int W, const f
         if (hipMalloc(&part.p, sizeof(double) * (size_t)inorm_patch_doubles(B, Ho * Wo, Cout)) != hipSuccess) return CF_ERR_HIP;
         p.st_partial = static_cast<double*>(part.p);
     }
-    hipError_t e = launch_conv(p, B, st, tile);
+    int tile_used = 0;
+    hipError_t e = launch_conv(p, B, st, tile, &tile_used);
     if (e != hipSuccess) return e == hipErrorInvalidValue ? CF_ERR_ARG : CF_ERR_HIP;
-    if (stats_out && launch_inorm_final(p.st_partial, (Ho * Wo + 31) / 32, B, Ho * Wo, Cout, eps, stats_out, st) != hipSuccess)
+    if (stats_out && launch_inorm_final(p.st_partial, conv_stats_chunks(p, tile_used), B, Ho * Wo, Cout, eps, stats_out, st) != hipSuccess)
         return CF_ERR_HIP;
     if (iters > 0 && ms_out) {   // timing loop for tools/conv_bench.py
         hipEvent_t a, b;

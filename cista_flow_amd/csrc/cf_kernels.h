@@ -75,6 +75,7 @@ struct ConvParams {
     // ---- B operand (packed weights [w_rows][Ktot], K contiguous) ----
     const float* w;
     const float* w_wino; // Winograd F(2x2,3x3) transform of w (launch_wino_weights; nullable): enables tile 40
+    long wino_gs;       // floats between the Winograd matrices of consecutive weight groups (w_div)
     const void* w16;    // f16 split copy of w (nullable; f16 modes fall back to splitting B while staging)
     long w_bs;          // weight stride between image groups (0 for ordinary weights; N*D for the correlation GEMM)
     int  w_div;         // images per weight group (<= 1: one matrix per image when w_bs != 0).  Two networks with the
@@ -117,6 +118,8 @@ const char* conv_tile_name(int tile);
 // U = G g G^T of a packed 3x3 matrix [rows][9][cin_pad] in conv_wino_kernel's block layout (wino_weight_floats floats)
 hipError_t launch_wino_weights(const float* w, float* u, int rows, int cin_pad, hipStream_t s);
 long wino_weight_floats(int rows, int cin_pad);
+// number of statistics partials per image a convolution with st_partial writes (tile = the tile launch_conv used)
+int conv_stats_chunks(const ConvParams& p, int tile);
 // f16 split copy of a packed weight matrix (same byte size, LDS chunk format [16 hi | 16 lo])
 hipError_t launch_split_weight_f16(const float* src, void* dst, long rows, int Ktot, hipStream_t s);
 

@@ -502,17 +502,19 @@ __device__ __forceinline__ void patch_tail(const ConvParams& p, const float* sW,
 // Fused InstanceNorm statistics: the wave's 32-pixel x 32-channel patch (raw accumulators, row stride EPI_S)
 // is summed down its columns in fp64 -- lane = channel, the two half-waves take 16 rows each -- over
 // v = acc + bias exactly as stored, and written to st_partial[b][patch][cout][2] (every element once).
+// mtab (nullable): row validity comes from the row -> pixel table and the patch is number `patch_id` of `npatch_` per image
+// (Winograd tiles); otherwise rows mrow0.. of the image and patch number mrow0 / 32 of ceil(M / 32)
 __device__ __forceinline__ void patch_stats(const ConvParams& p, const float* sW, int b, int mrow0, int nbase, int lane,
-                                            int M) {
+                                            int M, const int* mtab = nullptr, int patch_id = 0, int npatch_ = 0) {
     const int c = lane & 31, half = lane >> 5;
     const int n = nbase + c;
-    const int nvalid = M - mrow0;          // rows of this patch inside the image (<= 0: patch is all padding)
+    const int nvalid = mtab ? 32 : M - mrow0;          // rows of this patch inside the image (<= 0: patch is all padding)
     const float bv = (p.bias && n < p.cout) ? p.bias[(long)wgroup(p, b) * p.bias_gs + n] : 0.f;
     double s = 0.0, ss = 0.0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = half * 16 + r;
-        if (row < nvalid) {
+        if (mtab ? mtab[row] >= 0 : row < nvalid) {
             const double d = (double)(sW[row * EPI_S + c] + bv);
             s += d;
             ss += d * d;
@@ -521,11 +523,12 @@ __device__ __forceinline__ void patch_stats(const ConvParams& p, const float* sW
     s += __shfl_xor(s, 32);
     ss += __shfl_xor(ss, 32);
     if (half == 0 && nvalid > 0 && n < p.cout) {
-        const long npatch = (M + 31) >> 5;
+        const long npatch = mtab ? npatch_ : (M + 31) >> 5;
+        const long pid = mtab ? patch_id : (mrow0 >> 5);
         double2 o;
         o.x = s;
         o.y = ss;
-        *reinterpret_cast<double2*>(p.st_partial + (((long)b * npatch + (mrow0 >> 5)) * p.cout + n) * 2) = o;
+        *reinterpret_cast<double2*>(p.st_partial + (((long)b * npatch + pid) * p.cout + n) * 2) = o;
     }
 }
 
@@ -1486,7 +1489,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParams p) {
         a_pix[j] = ok ? iy * p.Win + ix : -1;
     }
     const int nchunk = p.cin_pad / WG_KC;
-    const __amdgpu_buffer_rsrc_t u_rsrc = make_rsrc(p.w_wino + (long)nblk * nchunk * WG_UV);
+    const __amdgpu_buffer_rsrc_t u_rsrc = make_rsrc(p.w_wino + (long)wgroup(p, b) * p.wino_gs + (long)nblk * nchunk * WG_UV);
 
     // chunk iterator over the channel segments (wave-uniform)
     int it_seg = 0, it_cs = 0;
@@ -1611,6 +1614,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParams p) {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     patch_tail(p, sW, b, 0, n0, lane, Ho * Wo, 0, 4, 1, 0, mtab);
+    if (p.st_partial) patch_stats(p, sW, b, 0, n0, lane, Ho * Wo, mtab, reg * 4 + wave, nreg * 4);
 }
 
 // U = G g G^T of a packed direct matrix w [rows][tap][cin_pad] (BatchNorm folds, stacking, interleaving already applied),
@@ -1652,9 +1656,16 @@ hipError_t launch_wino_weights(const float* w, float* u, int rows, int cin_pad, 
 }
 long wino_weight_floats(int rows, int cin_pad) { return (long)((rows + 31) / 32) * (cin_pad / WG_KC) * WG_UV; }
 
+// statistics partials a convolution with st_partial writes per image: one per 32-pixel patch, or per Winograd tile row
+int conv_stats_chunks(const ConvParams& p, int tile) {
+    if (tile == 40) return ((p.Wo + 2 * WG_TW - 1) / (2 * WG_TW)) * ((p.Ho + 2 * WG_TH - 1) / (2 * WG_TH)) * 4;
+    return (p.Ho * p.Wo + 31) / 32;
+}
+
 static bool wino_ok(const ConvParams& p) {
     if (p.a_mode != A_NHWC || p.prec != 0 || !p.w_wino || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.padT != 1 || p.padL != 1) return false;
-    if (p.Ho != p.Hin || p.Wo != p.Win || p.Hin < 12 || p.Win < 12 || p.st_partial || p.w_bs != 0 || p.bias_gs != 0) return false;
+    if (p.Ho != p.Hin || p.Wo != p.Win || p.Hin < 12 || p.Win < 12) return false;
+    if (p.w_bs != 0 && p.w_div <= 1) return false;          // per-image matrices (correlation GEMM); weight groups are fine
     for (int i = 0; i < p.nseg; ++i)
         if (p.seg_c[i] % WG_KC) return false;
     return true;

@@ -369,7 +369,8 @@ hipError_t launch_inorm_stats(const float* x, int ld, long bs, int B, int HW, in
 // number of doubles launch_inorm_stats needs in `partial`
 long inorm_partial_doubles(int B, int HW, int C) { return (long)B * ((HW + IN_CHUNK - 1) / IN_CHUNK) * C * 2; }
 // ... and a convolution with fused statistics (ConvParams::st_partial, 32-pixel patches)
-long inorm_patch_doubles(int B, int HW, int C) { return (long)B * ((HW + 31) / 32) * C * 2; }
+// (x2: the Winograd kernel writes one partial per tile row of its 8 x 16 regions, up to ~1.3x as many on ragged sizes)
+long inorm_patch_doubles(int B, int HW, int C) { return (long)B * ((HW + 31) / 32) * C * 2 * 2 + 1024; }
 
 __global__ __launch_bounds__(256) void inorm_apply_kernel(const float* __restrict__ x, int ld, long bs,
                                                           const float* __restrict__ stats, const float* __restrict__ res,

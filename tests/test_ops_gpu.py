@@ -138,6 +138,8 @@ STATS_CASES = [
     (5, 64, 7, 7, 2, 3, 2, 0, 64, 80),       # conv1 of the encoders: planar gather mode
     (96, 96, 3, 3, 1, 1, 0, 34, 24, 32),     # 32x96 split-K tile (three sub-tiles per wave), register reduction path
     (64, 96, 3, 3, 2, 1, 0, 0, 96, 128),     # ... as the launcher picks it for the 96-channel stage
+    (64, 64, 3, 3, 1, 1, 0, 40, 48, 64),     # Winograd tile: one partial per tile row of an 8 x 16 region
+    (96, 96, 3, 3, 1, 1, 0, 40, 21, 37),     # ... ragged regions
 ]
 
 
