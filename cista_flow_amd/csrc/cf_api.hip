@@ -132,6 +132,7 @@ struct cf_handle {
     int enc_group_sel = -1;        // >= 0: the encoder being issued uses this matrix of its grouped PackedConvs
     int last_tile = 0;             // tile kind of the last run_conv launch (statistics chunk count of the Winograd tile)
     bool enc_pair = false;         // CF_ENC_PAIR=1: fnet + enet as one 2B batch instead of two streams
+    bool wino = true;              // CF_WINO=0: 3x3 convolutions on the direct implicit-GEMM kernel instead of Winograd F(2x2,3x3)
     // CF_PHASES=1 (tuning aid): HIP events on the caller's stream at the phase boundaries of cf_step, averaged
     // and printed to stderr by cf_destroy
     bool phases = false;
@@ -240,6 +241,7 @@ static hipError_t run_conv(cf_handle* h, const ConvParams& p_in, int batch, hipS
         if (p.aux3) p.aux3 += b0 * p.aux3_bs;
         if (p.addend) p.addend += b0 * p.addend_bs;
     }
+    if (h && !h->wino) p.w_wino = nullptr;
     if (h && h->enc_tile_batch > 0) p.tile_batch = h->enc_tile_batch;
     if (p.w_div < 0 && h && h->enc_group_sel >= 0) {      // one network of a grouped PackedConv on its own: fixed matrix
         p.w += (long)h->enc_group_sel * p.w_bs;
@@ -836,6 +838,7 @@ extern "C" int cf_create(cf_handle** out, const cf_config* cfg) {
         return CF_ERR_HIP;
     }
     if (const char* e = getenv("CF_ENC_PAIR")) h->enc_pair = atoi(e) != 0;      // before the arena is laid out
+    if (const char* e = getenv("CF_WINO")) h->wino = atoi(e) != 0;
     if (const char* e = getenv("CF_ARENA_SKEW")) h->arena.skew = (size_t)atol(e) & ~size_t(255);
     if (const char* e = getenv("CF_ARENA_ALIGN")) {
         const size_t a = (size_t)atol(e);

@@ -1937,15 +1937,6 @@ static int default_sched() {
     return v;
 }
 
-static int default_wino() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("CF_WINO");
-        v = e ? atoi(e) : 0;
-    }
-    return v;
-}
-
 static int default_dma() {
     static int v = -1;
     if (v < 0) {
@@ -2018,7 +2009,15 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
         if (tile_used) *tile_used = 7;
         return launch_smalln(p, batch, s, tile == 15);
     }
-    if (tile == 0 && default_wino() && wino_ok(p)) tile = 40;
+    // 3x3 / stride 1 layers whose caller supplied the transformed weights run as Winograd F(2x2,3x3): 1.2-1.55x the direct
+    // kernel (tools/conv_bench.py TILES=0,40) once the launch has >= ~128 workgroups; below that a workgroup's chain of
+    // Cin/8 chunk steps (~1.4 us each, nothing to alternate with on its CU) is longer than the direct kernel's launch
+    // (1/8-resolution maps at B <= 4: measured 0.7-1.0x)
+    if (tile == 0 && wino_ok(p)) {
+        const long tb = p.tile_batch > 0 ? p.tile_batch : batch;
+        const long wg = (long)((p.Wo + 2 * WG_TW - 1) / (2 * WG_TW)) * ((p.Ho + 2 * WG_TH - 1) / (2 * WG_TH)) * ((p.cout + 31) / 32) * tb;
+        if (wg >= 128) tile = 40;
+    }
     if (tile == 0) {
         // Pick the largest tile that still yields >= ~2 workgroups per CU (measured with tools/conv_bench.py on
         // MI355X): big tiles reuse operands best, but a launch with fewer than ~512 workgroups leaves CUs idle,

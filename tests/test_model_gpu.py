@@ -571,3 +571,25 @@ def test_encoder_pair_mode_matches_two_stream_mode(gpu, monkeypatch):
         for a, b in zip(res[(kind, "0")], res[(kind, "1")]):
             for x, y in zip(a[:4], b[:4]):
                 assert gu.rel_err(x.cpu(), y.cpu()) < 2e-5, kind
+
+
+@pytest.mark.parametrize("name,kind", [("eiflow_100x124.npz", "eiflow"), ("eraft_100x124.npz", "eraft"), ("idnet_68x92.npz", "idnet")])
+def test_direct_conv_path_golden(gpu, monkeypatch, name, kind):
+    """CF_WINO=0: every 3x3 convolution on the direct implicit-GEMM kernel (the default runs them as Winograd
+    F(2x2,3x3)) -- the reference goldens must hold for both, and the two paths agree to the transforms' rounding."""
+    g = gu.load(name)
+    H, W, B, frames, seed = [int(v) for v in g["meta"]]
+    outs = {}
+    for wino in ("0", "1"):
+        monkeypatch.setenv("CF_WINO", wino)
+        m = _build(kind, H, W, seed, gpu)
+        evs = [torch.from_numpy(g["ev_%d" % t]).to(gpu) for t in range(frames)]
+        old = wu.synth_events(B, 5, H, W, seed * 1000 + 999).to(gpu) if kind == "eraft" else None
+        with torch.no_grad():
+            outs[wino] = _drive(kind, m, evs, old, gpu)
+        for t in range(frames):
+            assert gu.rel_err(outs[wino][t][0].cpu(), g["I_%d" % t]) < TOL, (wino, t)
+            assert gu.rel_err(outs[wino][t][1].cpu(), g["flow_%d" % t]) < TOL, (wino, t)
+            assert gu.rel_err(gu.sub(outs[wino][t][2].cpu()), g["z_%d" % t]) < TOL, (wino, t)
+    for a, b in zip(outs["0"], outs["1"]):
+        assert gu.rel_err(a[0].cpu(), b[0].cpu()) < 1e-4 and gu.rel_err(a[2].cpu(), b[2].cpu()) < 1e-4

@@ -46,6 +46,7 @@ PREC = int(os.environ.get("PREC", "0"))
 
 def run(shape, tile, iters=20):
     name, B, Cin, H, W, Cout, KH, KW, stride, pT, pL, pm = shape
+    B = int(os.environ.get("BATCH", B))
     x = torch.randn(B, H, W, Cin, device=dev)
     w = torch.randn(Cout, Cin, KH, KW, device=dev) / (Cin * KH * KW) ** 0.5
     b = torch.randn(Cout, device=dev)
