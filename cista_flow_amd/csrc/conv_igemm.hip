@@ -1435,8 +1435,13 @@ void conv_dma_kernel(const ConvParams p) {
 //           common fused epilogue (patch_tail) with a row -> pixel table.
 // Two workgroups per CU (78 KB LDS each): one transforms while the other multiplies.
 // ---------------------------------------------------------------------------------------------------------
-static constexpr int WG_TH = 4, WG_TW = 8;                  // tiles per region
-static constexpr int WG_PR = 2 * WG_TH + 2, WG_PC = 2 * WG_TW + 2, WG_PIX = WG_PR * WG_PC;   // 10 x 18 = 180 patch pixels
+// tiles per region: 4 x 8 (8 x 16 output pixels, "wide") or 8 x 4 (16 x 8, "tall"), whichever wastes fewer pixels on the
+// image's ragged edge (90 x 120: 96 x 128 = +13.8 % wide, 96 x 120 = +6.7 % tall); the patch is 10 x 18 or 18 x 10 pixels
+static constexpr int WG_PIX = 180;
+__host__ __device__ inline int wino_tall(int Ho, int Wo) {
+    const long wide = (long)((Ho + 7) / 8 * 8) * ((Wo + 15) / 16 * 16), tall = (long)((Ho + 15) / 16 * 16) * ((Wo + 7) / 8 * 8);
+    return tall < wide ? 1 : 0;
+}
 static constexpr int WG_KC = 8;                             // channels per chunk
 static constexpr int WG_RAW = 384 * 4;                      // floats per raw buffer: 360 16-byte slots, padded to whole wave-instructions
 static constexpr int WG_UV = 16 * 32 * WG_KC;               // floats per U / V buffer (4096)
@@ -1452,7 +1457,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParams p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Ho = p.Ho, Wo = p.Wo;
-    const int nrx = (Wo + 2 * WG_TW - 1) / (2 * WG_TW), nry = (Ho + 2 * WG_TH - 1) / (2 * WG_TH);
+    const int tall = wino_tall(Ho, Wo);
+    const int TWr = tall ? 4 : 8;                            // tile columns of a region (tile rows = 32 / TWr)
+    const int RH = tall ? 16 : 8, RW = tall ? 8 : 16;        // region size in output pixels
+    const int PC = RW + 2;                                   // patch columns (rows = RH + 2; PC * (RH + 2) = 180 either way)
+    const int nrx = (Wo + RW - 1) / RW, nry = (Ho + RH - 1) / RH;
     const int nreg = nrx * nry;
     const int nt = (p.cout + 31) / 32;
     int tile_id = blockIdx.x;
@@ -1466,7 +1475,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParams p) {
     const int rest = tile_id / nt;
     const int reg = rest % nreg;
     const int b = rest / nreg;
-    const int oy0 = (reg / nrx) * (2 * WG_TH), ox0 = (reg % nrx) * (2 * WG_TW);
+    const int oy0 = (reg / nrx) * RH, ox0 = (reg % nrx) * RW;
     const int n0 = nblk * 32;
 
     // ---- raw patch DMA slots: slot s -> patch pixel s >> 1, channel quad s & 1 ----
@@ -1477,7 +1486,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParams p) {
         const int sl = tid + 256 * j;
         const int pix = sl >> 1;
         a_q[j] = (unsigned)(sl & 1) * 16u;
-        const int py = pix / WG_PC, px = pix - py * WG_PC;
+        const int py = pix / PC, px = pix - py * PC;
         int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
         bool ok = sl < 2 * WG_PIX && iy <= p.Hin && ix <= p.Win;      // beyond the halo of the last row / column: unused
         if (p.pad_mode == 1) {
@@ -1529,9 +1538,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-    // transform mapping: tile (row = wave, column = lane >> 3), channel lane & 7
+    // transform mapping: tile t = wave * 8 + (lane >> 3) = (ty, tx) of the region, channel lane & 7
     const int tcol = lane >> 3, tc = lane & 7;
-    const int rsrc0 = (2 * wave * WG_PC + 2 * tcol) * WG_KC + tc;                       // patch pixel (2 ty, 2 tx), channel tc
+    const int tt = wave * 8 + tcol, tty = tt / TWr, ttx = tt - tty * TWr;
+    const int rsrc0 = (2 * tty * PC + 2 * ttx) * WG_KC + tc;                            // patch pixel (2 ty, 2 tx), channel tc
     const int vdst = ((wave * 8 + tcol) * WG_KC) + ((((tc >> 2) ^ (wave & 1)) << 2) | (tc & 3));   // + pos * 32 * 8
     // fragment addresses (floats): row lr of position (wave, j), k quad lh (swizzled by (lr >> 3) & 1)
     const int lr = lane & 31, lh = lane >> 5;
@@ -1549,7 +1559,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParams p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) d[i][j] = r[(i * WG_PC + j) * WG_KC];
+                for (int j = 0; j < 4; ++j) d[i][j] = r[(i * PC + j) * WG_KC];
             float t[4][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -1607,7 +1617,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParams p) {
     }
     if (lane < 32) {
         const int tl = lane >> 2, a = (lane >> 1) & 1, bb = lane & 1;
-        const int oy = oy0 + 2 * wave + a, ox = ox0 + 2 * tl + bb;
+        const int t = wave * 8 + tl, ty = t / TWr, tx = t - ty * TWr;
+        const int oy = oy0 + 2 * ty + a, ox = ox0 + 2 * tx + bb;
         mtab[lane] = (oy < Ho && ox < Wo) ? oy * Wo + ox : -1;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1655,10 +1666,13 @@ hipError_t launch_wino_weights(const float* w, float* u, int rows, int cin_pad, 
     return hipGetLastError();
 }
 long wino_weight_floats(int rows, int cin_pad) { return (long)((rows + 31) / 32) * (cin_pad / WG_KC) * WG_UV; }
+static int wino_regions(int Ho, int Wo) {
+    return wino_tall(Ho, Wo) ? ((Ho + 15) / 16) * ((Wo + 7) / 8) : ((Ho + 7) / 8) * ((Wo + 15) / 16);
+}
 
 // statistics partials a convolution with st_partial writes per image: one per 32-pixel patch, or per Winograd tile row
 int conv_stats_chunks(const ConvParams& p, int tile) {
-    if (tile == 40) return ((p.Wo + 2 * WG_TW - 1) / (2 * WG_TW)) * ((p.Ho + 2 * WG_TH - 1) / (2 * WG_TH)) * 4;
+    if (tile == 40) return wino_regions(p.Ho, p.Wo) * 4;
     return (p.Ho * p.Wo + 31) / 32;
 }
 
@@ -1673,7 +1687,7 @@ static bool wino_ok(const ConvParams& p) {
 
 static hipError_t launch_wino(const ConvParams& p, int batch, hipStream_t s) {
     if (!wino_ok(p)) return hipErrorInvalidValue;
-    const long nreg = (long)((p.Wo + 2 * WG_TW - 1) / (2 * WG_TW)) * ((p.Ho + 2 * WG_TH - 1) / (2 * WG_TH));
+    const long nreg = wino_regions(p.Ho, p.Wo);
     const long wgs = nreg * ((p.cout + 31) / 32) * batch;
     if (wgs <= 0 || wgs >= 0x7FFFFFFFL) return hipErrorInvalidValue;
     g_last_launch.threads = wgs * 256;
@@ -2015,7 +2029,7 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
     // (1/8-resolution maps at B <= 4: measured 0.7-1.0x)
     if (tile == 0 && wino_ok(p)) {
         const long tb = p.tile_batch > 0 ? p.tile_batch : batch;
-        const long wg = (long)((p.Wo + 2 * WG_TW - 1) / (2 * WG_TW)) * ((p.Ho + 2 * WG_TH - 1) / (2 * WG_TH)) * ((p.cout + 31) / 32) * tb;
+        const long wg = (long)wino_regions(p.Ho, p.Wo) * ((p.cout + 31) / 32) * tb;
         if (wg >= 128) tile = 40;
     }
     if (tile == 0) {
