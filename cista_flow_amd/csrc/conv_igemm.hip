@@ -1446,12 +1446,27 @@ static constexpr int WG_KC = 8;                             // channels per chun
 static constexpr int WG_RAW = 384 * 4;                      // floats per raw buffer: 360 16-byte slots, padded to whole wave-instructions
 static constexpr int WG_UV = 16 * 32 * WG_KC;               // floats per U / V buffer (4096)
 
-__global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParams p) {
-    __shared__ __attribute__((aligned(16))) float sV[WG_UV];
-    __shared__ __attribute__((aligned(16))) float sU[2 * WG_UV];            // reused as the cross-wave exchange X[4][2][32][32]
-    __shared__ __attribute__((aligned(16))) float sRaw[2 * WG_RAW];
-    __shared__ __attribute__((aligned(16))) float sPatch[4 * 32 * EPI_S];
-    __shared__ int sMtab[4 * 32];
+__global__ __launch_bounds__(256, 3) void conv_wino_kernel(const ConvParams p) {
+#ifdef CF_STAMP
+    const long long t_begin = __builtin_readcyclecounter();
+    const long long r_begin = (long long)__builtin_amdgcn_s_memrealtime();
+    long long st_wait = 0, st_bar = 0, st_issue = 0;
+#endif
+    // ONE __shared__ object on purpose: with several, the compiler's LDS lowering tags each with an alias scope, its waitcnt
+    // pass then tracks the LDS-DMA writes per scope and puts s_waitcnt vmcnt(0) in front of the first ds_read that follows a
+    // DMA issue -- which serialises the prefetch of chunk k+1 with the transform of chunk k.  Without scopes the DMA hand-off
+    // is left to the explicit vmcnt waits + barriers below (as in conv_dma_kernel).
+    //   sV    [16 pos][32 tiles][8 k]   transformed input of the current chunk          } after the loop: the cross-wave
+    //   sRaw  [2][WG_RAW]               raw patches (LDS-DMA ring of two)               } exchange X[4][2][32][32]
+    //   sPatch, sMtab                   epilogue patches and their row -> pixel tables
+    // U never enters LDS: wave w owns positions (w, 0..3), nobody else reads their weights, so each lane fetches its own
+    // MFMA B fragments (16 bytes, L2 hits) straight into registers one chunk ahead.
+    constexpr int WG_A = WG_UV + 2 * WG_RAW > 4 * 2 * 32 * 32 ? WG_UV + 2 * WG_RAW : 4 * 2 * 32 * 32;
+    __shared__ __attribute__((aligned(16))) float smem[WG_A + 4 * 32 * EPI_S + 4 * 32];
+    float* const sV = smem;
+    float* const sRaw = sV + WG_UV;
+    float* const sPatch = smem + WG_A;
+    int* const sMtab = reinterpret_cast<int*>(sPatch + 4 * 32 * EPI_S);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1460,7 +1475,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParams p) {
     const int tall = wino_tall(Ho, Wo);
     const int TWr = tall ? 4 : 8;                            // tile columns of a region (tile rows = 32 / TWr)
     const int RH = tall ? 16 : 8, RW = tall ? 8 : 16;        // region size in output pixels
-    const int PC = RW + 2;                                   // patch columns (rows = RH + 2; PC * (RH + 2) = 180 either way)
+    const int PC = RW + 2, PCh = PC >> 1;                    // patch columns (rows = RH + 2; PC * (RH + 2) = 180 either way)
     const int nrx = (Wo + RW - 1) / RW, nry = (Ho + RH - 1) / RH;
     const int nreg = nrx * nry;
     const int nt = (p.cout + 31) / 32;
@@ -1478,15 +1493,18 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParams p) {
     const int oy0 = (reg / nrx) * RH, ox0 = (reg % nrx) * RW;
     const int n0 = nblk * 32;
 
-    // ---- raw patch DMA slots: slot s -> patch pixel s >> 1, channel quad s & 1 ----
+    // ---- raw patch DMA slots: slot s -> patch cell s >> 1, channel quad s & 1.  Cells of a patch row are stored even columns
+    // first, then odd columns (cell = py * PC + (px >> 1) + (px & 1) * PC/2): the four tiles a 32-lane group reads at once
+    // (columns 2 tx + j) are then neighbours, 8 consecutive 16-byte slots = all 32 banks, instead of two tiles per bank ----
     int a_pix[2];
     unsigned a_q[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int sl = tid + 256 * j;
-        const int pix = sl >> 1;
+        const int cell = sl >> 1;
         a_q[j] = (unsigned)(sl & 1) * 16u;
-        const int py = pix / PC, px = pix - py * PC;
+        const int py = cell / PC, pc = cell - py * PC;
+        const int px = pc < PCh ? 2 * pc : 2 * (pc - PCh) + 1;
         int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
         bool ok = sl < 2 * WG_PIX && iy <= p.Hin && ix <= p.Win;      // beyond the halo of the last row / column: unused
         if (p.pad_mode == 1) {
@@ -1504,7 +1522,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParams p) {
     int it_seg = 0, it_cs = 0;
     const float* seg_base = p.in[0] + (long)b * p.seg_bs[0];
     int seg_ld = p.seg_ld[0], seg_cn = p.seg_c[0];
-    auto issue = [&](int chunk, int buf) __attribute__((always_inline)) {
+    auto issue_raw = [&](int buf) __attribute__((always_inline)) {
         const __amdgpu_buffer_rsrc_t rs = make_rsrc(seg_base);
         const unsigned ld4 = (unsigned)seg_ld * 4u, so = (unsigned)it_cs * 4u;
         float* rbase = sRaw + buf * WG_RAW;
@@ -1515,10 +1533,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParams p) {
                 dma16_to_lds(rs, rbase + (256 * j + 64 * wave) * 4, off, so);
             }
         }
-        float* ubase = sU + buf * WG_UV;
-#pragma unroll
-        for (int it = 0; it < 4; ++it)
-            dma16_to_lds(u_rsrc, ubase + (256 * it + 64 * wave) * 4, (unsigned)(tid + 256 * it) * 16u, (unsigned)chunk * (WG_UV * 4u));
         // advance to the next chunk
         it_cs += WG_KC;
         if (it_cs >= seg_cn) {
@@ -1541,17 +1555,34 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParams p) {
     // transform mapping: tile t = wave * 8 + (lane >> 3) = (ty, tx) of the region, channel lane & 7
     const int tcol = lane >> 3, tc = lane & 7;
     const int tt = wave * 8 + tcol, tty = tt / TWr, ttx = tt - tty * TWr;
-    const int rsrc0 = (2 * tty * PC + 2 * ttx) * WG_KC + tc;                            // patch pixel (2 ty, 2 tx), channel tc
+    const int rsrc0 = (2 * tty * PC + ttx) * WG_KC + tc;                                // patch cell of pixel (2 ty, 2 tx), channel tc
     const int vdst = ((wave * 8 + tcol) * WG_KC) + ((((tc >> 2) ^ (wave & 1)) << 2) | (tc & 3));   // + pos * 32 * 8
     // fragment addresses (floats): row lr of position (wave, j), k quad lh (swizzled by (lr >> 3) & 1)
     const int lr = lane & 31, lh = lane >> 5;
     const int frag = lr * WG_KC + ((lh ^ ((lr >> 3) & 1)) << 2);
+    const unsigned uoff = (unsigned)((wave * 4) * 256 + frag) * 4u;                     // + j KiB: position (wave, j) of a chunk's U block
 
-    issue(0, 0);
-    for (int k = 0; k < nchunk; ++k) {
-        wait_vmcnt0();
-        raw_barrier();                              // chunk k has landed for everybody; iteration k-1 is finished everywhere
-        if (k + 1 < nchunk) issue(k + 1, (k + 1) & 1);
+    auto load_u = [&](int chunk, f32x4 (&dst)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[j] = buf_load4(u_rsrc, uoff + 1024u * j, (unsigned)chunk * (WG_UV * 4u));
+    };
+    // one chunk: hand-off of raw(k), prefetch of chunk k+1 (raw by LDS-DMA, then U into `nxt`), transform, 16 MFMAs with `cur`
+    auto chunk_step = [&](int k, const f32x4 (&cur)[4], f32x4 (&nxt)[4]) __attribute__((always_inline)) {
+#ifdef CF_STAMP
+        const long long t0 = __builtin_readcyclecounter();
+#endif
+        // in flight, oldest first: raw(k), then the four U(k) loads -- raw(k) has landed once at most four are outstanding
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        raw_barrier();                              // raw(k) has landed for everybody; iteration k-1 is finished everywhere
+#ifdef CF_STAMP
+        const long long t1 = __builtin_readcyclecounter();
+#endif
+        if (k + 1 < nchunk) {
+            issue_raw((k + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);      // keep "raw before U" in issue order: the vmcnt(4) above counts on it
+            load_u(k + 1, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // ---- input transform V = B^T d B ----
         {
             const float* r = sRaw + (k & 1) * WG_RAW + rsrc0;
@@ -1559,7 +1590,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParams p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) d[i][j] = r[(i * PC + j) * WG_KC];
+                for (int j = 0; j < 4; ++j) d[i][j] = r[(i * PC + (j >> 1) + (j & 1) * PCh) * WG_KC];
             float t[4][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -1577,25 +1608,45 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParams p) {
             }
         }
         wait_lgkm0();                               // this wave's V writes are done ...
-        raw_barrier();                              // ... and everybody's (NOT __syncthreads: it would drain the DMA of chunk k+1)
+#ifdef CF_STAMP
+        const long long t2 = __builtin_readcyclecounter();
+#endif
+        raw_barrier();                              // ... and everybody's (NOT __syncthreads: it would drain the prefetch)
+#ifdef CF_STAMP
+        st_wait += t1 - t0;
+        st_bar += __builtin_readcyclecounter() - t2;
+        st_issue += t2 - t1;
+#endif
         // ---- 16 MFMAs: positions (wave, 0..3) ----
         {
-            const float* ub = sU + (k & 1) * WG_UV;
-            f32x4 af[4], bf[4];
+            f32x4 af[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                af[j] = *reinterpret_cast<const f32x4*>(sV + (wave * 4 + j) * 256 + frag);
-                bf[j] = *reinterpret_cast<const f32x4*>(ub + (wave * 4 + j) * 256 + frag);
-            }
+            for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const f32x4*>(sV + (wave * 4 + j) * 256 + frag);
 #pragma unroll
             for (int s2 = 0; s2 < 4; ++s2)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][s2], bf[j][s2], acc[j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][s2], cur[j][s2], acc[j], 0, 0, 0);
         }
+    };
+
+    f32x4 bu0[4], bu1[4];
+    issue_raw(0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_u(0, bu0);
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef CF_STAMP
+    const long long t_loop_begin = __builtin_readcyclecounter();
+#endif
+    for (int k = 0; k < nchunk; k += 2) {
+        chunk_step(k, bu0, bu1);
+        if (k + 1 < nchunk) chunk_step(k + 1, bu1, bu0);
     }
-    __syncthreads();                                // every wave is done with U before it becomes the exchange buffer
+#ifdef CF_STAMP
+    const long long t_loop_end = __builtin_readcyclecounter();
+#endif
+    __syncthreads();                                // every wave is done with V before it becomes the exchange buffer
     // ---- output transform, j direction (in registers): R[0] = M0 + M1 + M2, R[1] = M1 - M2 - M3 ----
-    float* X = sU;                                  // X[i = wave][bcol][tile 32][cout 32]
+    float* X = smem;                                // X[i = wave][bcol][tile 32][cout 32], over V + raw
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int trow = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -1626,6 +1677,15 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvParams p) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     patch_tail(p, sW, b, 0, n0, lane, Ho * Wo, 0, 4, 1, 0, mtab);
     if (p.st_partial) patch_stats(p, sW, b, 0, n0, lane, Ho * Wo, mtab, reg * 4 + wave, nreg * 4);
+#ifdef CF_STAMP
+    if (p.stamp && lane == 0) {      // [DMA wait + barrier, second barrier, issue + transform, prologue, chunks, loop, tail, MHz]
+        long long* q = p.stamp + ((long)blockIdx.x * 4 + wave) * 8;
+        q[0] = st_wait; q[1] = st_bar; q[2] = st_issue; q[3] = t_loop_begin - t_begin; q[4] = nchunk;
+        q[5] = t_loop_end - t_loop_begin; q[6] = __builtin_readcyclecounter() - t_loop_end;
+        const long long dr = (long long)__builtin_amdgcn_s_memrealtime() - r_begin;
+        q[7] = dr > 0 ? ((__builtin_readcyclecounter() - t_begin) * 100) / dr : 0;
+    }
+#endif
 }
 
 // U = G g G^T of a packed direct matrix w [rows][tap][cin_pad] (BatchNorm folds, stacking, interleaving already applied),

@@ -34,6 +34,11 @@ for case in CASES.split(","):
     n = d[:, 4].mean().item()
     m = d.mean(0)
     comp = (m[5] - m[0] - m[1] - m[2]) / n
+    if int(tile) == 40:     # conv_wino_kernel: [DMA wait + first barrier, second barrier, issue + input transform]
+        print("%-34s tile 40  %7.1f us %5.1f TF | chunks %3d | per chunk: dma-wait+barrier %4.0f  issue+transform %4.0f  barrier %4.0f  "
+              "frag reads + 16 mfma %4.0f | prologue %6.0f  loop %7.0f  tail %6.0f cycles | shader clock %4.0f MHz" % (
+                  shape[0], r[0], r[1], n, m[0] / n, m[2] / n, m[1] / n, comp, m[3], m[5], m[6], m[7]), flush=True)
+        continue
     print("%-34s tile %2d  %7.1f us %5.1f TF | stages %3d | per stage: vmcnt-wait %4.0f  barrier %4.0f  issue %4.0f  lds+mfma %4.0f"
           " | prologue %6.0f  loop %7.0f  tail %6.0f cycles | shader clock %4.0f MHz (median %4.0f)" % (
               shape[0], int(tile), r[0], r[1], n, m[0] / n, m[1] / n, m[2] / n, comp, m[3], m[5], m[6], m[7], d[:, 7].median().item()), flush=True)
