@@ -1446,7 +1446,10 @@ static constexpr int WG_KC = 8;                             // channels per chun
 static constexpr int WG_RAW = 384 * 4;                      // floats per raw buffer: 360 16-byte slots, padded to whole wave-instructions
 static constexpr int WG_UV = 16 * 32 * WG_KC;               // floats per U / V buffer (4096)
 
-__global__ __launch_bounds__(256, 3) void conv_wino_kernel(const ConvParams p) {
+#ifndef WG_ABL
+#define WG_ABL 0
+#endif
+__global__ __launch_bounds__(256, 4) void conv_wino_kernel(const ConvParams p) {
 #ifdef CF_STAMP
     const long long t_begin = __builtin_readcyclecounter();
     const long long r_begin = (long long)__builtin_amdgcn_s_memrealtime();
@@ -1456,17 +1459,19 @@ __global__ __launch_bounds__(256, 3) void conv_wino_kernel(const ConvParams p) {
     // pass then tracks the LDS-DMA writes per scope and puts s_waitcnt vmcnt(0) in front of the first ds_read that follows a
     // DMA issue -- which serialises the prefetch of chunk k+1 with the transform of chunk k.  Without scopes the DMA hand-off
     // is left to the explicit vmcnt waits + barriers below (as in conv_dma_kernel).
-    //   sV    [16 pos][32 tiles][8 k]   transformed input of the current chunk          } after the loop: the cross-wave
-    //   sRaw  [2][WG_RAW]               raw patches (LDS-DMA ring of two)               } exchange X[4][2][32][32]
-    //   sPatch, sMtab                   epilogue patches and their row -> pixel tables
-    // U never enters LDS: wave w owns positions (w, 0..3), nobody else reads their weights, so each lane fetches its own
-    // MFMA B fragments (16 bytes, L2 hits) straight into registers one chunk ahead.
+    //   sV    [16 pos][32 tiles][8 k]   transformed input of the current chunk   } after the loop: the cross-wave exchange
+    //   sRaw  [2][WG_RAW]               raw patches (LDS-DMA ring of two)        } X[4][2][32][32], then the epilogue patches
+    //   sMtab                           row -> pixel tables of the epilogue patches
+    // 32.5 KB and <= 128 registers: four workgroups per CU, so that the transform / prologue / epilogue phases of one hide
+    // behind the MFMAs of the others.  U never enters LDS: wave w owns positions (w, 0..3), nobody else reads their weights,
+    // so each lane fetches its own MFMA B fragments (16 bytes, L2 hits) straight into registers while it transforms.
     constexpr int WG_A = WG_UV + 2 * WG_RAW > 4 * 2 * 32 * 32 ? WG_UV + 2 * WG_RAW : 4 * 2 * 32 * 32;
-    __shared__ __attribute__((aligned(16))) float smem[WG_A + 4 * 32 * EPI_S + 4 * 32];
+    static_assert(4 * 32 * EPI_S <= WG_A, "the epilogue patches overlay the exchange buffer");
+    __shared__ __attribute__((aligned(16))) float smem[WG_A + 4 * 32];
     float* const sV = smem;
     float* const sRaw = sV + WG_UV;
-    float* const sPatch = smem + WG_A;
-    int* const sMtab = reinterpret_cast<int*>(sPatch + 4 * 32 * EPI_S);
+    float* const sPatch = smem;
+    int* const sMtab = reinterpret_cast<int*>(smem + WG_A);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1566,24 +1571,27 @@ __global__ __launch_bounds__(256, 3) void conv_wino_kernel(const ConvParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) dst[j] = buf_load4(u_rsrc, uoff + 1024u * j, (unsigned)chunk * (WG_UV * 4u));
     };
-    // one chunk: hand-off of raw(k), prefetch of chunk k+1 (raw by LDS-DMA, then U into `nxt`), transform, 16 MFMAs with `cur`
-    auto chunk_step = [&](int k, const f32x4 (&cur)[4], f32x4 (&nxt)[4]) __attribute__((always_inline)) {
+    // one chunk: hand-off of raw(k); U(k) into registers, then the LDS-DMA of raw(k+1); transform; 16 MFMAs
+    f32x4 bu[4] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}};
+    auto chunk_step = [&](int k) __attribute__((always_inline)) {
 #ifdef CF_STAMP
         const long long t0 = __builtin_readcyclecounter();
 #endif
-        // in flight, oldest first: raw(k), then the four U(k) loads -- raw(k) has landed once at most four are outstanding
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        wait_vmcnt0();
         raw_barrier();                              // raw(k) has landed for everybody; iteration k-1 is finished everywhere
 #ifdef CF_STAMP
         const long long t1 = __builtin_readcyclecounter();
 #endif
-        if (k + 1 < nchunk) {
-            issue_raw((k + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);      // keep "raw before U" in issue order: the vmcnt(4) above counts on it
-            load_u(k + 1, nxt);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+#if !(WG_ABL & 2)
+        load_u(k, bu);
+#endif
+        __builtin_amdgcn_sched_barrier(0);          // U(k) before raw(k+1) in issue order: the MFMAs then wait for U(k) only
+#if !(WG_ABL & 8)
+        if (k + 1 < nchunk) issue_raw((k + 1) & 1);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
         // ---- input transform V = B^T d B ----
+#if !(WG_ABL & 1)
         {
             const float* r = sRaw + (k & 1) * WG_RAW + rsrc0;
             float d[4][4];
@@ -1607,6 +1615,7 @@ __global__ __launch_bounds__(256, 3) void conv_wino_kernel(const ConvParams p) {
                 sV[(i * 4 + 3) * 256 + vdst] = t[i][1] - t[i][3];
             }
         }
+#endif
         wait_lgkm0();                               // this wave's V writes are done ...
 #ifdef CF_STAMP
         const long long t2 = __builtin_readcyclecounter();
@@ -1625,24 +1634,25 @@ __global__ __launch_bounds__(256, 3) void conv_wino_kernel(const ConvParams p) {
 #pragma unroll
             for (int s2 = 0; s2 < 4; ++s2)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][s2], cur[j][s2], acc[j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][s2], bu[j][s2], acc[j], 0, 0, 0);
         }
     };
 
-    f32x4 bu0[4], bu1[4];
     issue_raw(0);
-    __builtin_amdgcn_sched_barrier(0);
-    load_u(0, bu0);
-    __builtin_amdgcn_sched_barrier(0);
 #ifdef CF_STAMP
     const long long t_loop_begin = __builtin_readcyclecounter();
 #endif
-    for (int k = 0; k < nchunk; k += 2) {
-        chunk_step(k, bu0, bu1);
-        if (k + 1 < nchunk) chunk_step(k + 1, bu1, bu0);
-    }
+    for (int k = 0; k < nchunk; ++k) chunk_step(k);
 #ifdef CF_STAMP
     const long long t_loop_end = __builtin_readcyclecounter();
+#endif
+#if WG_ABL & 4
+    {
+        float sum = 0.f;
+        for (int j = 0; j < 4; ++j) for (int r = 0; r < 16; ++r) sum += acc[j][r];
+        if (sum == 12345.f) p.out[tid] = sum;
+        return;
+    }
 #endif
     __syncthreads();                                // every wave is done with V before it becomes the exchange buffer
     // ---- output transform, j direction (in registers): R[0] = M0 + M1 + M2, R[1] = M1 - M2 - M3 ----
@@ -1657,6 +1667,7 @@ __global__ __launch_bounds__(256, 3) void conv_wino_kernel(const ConvParams p) {
     // ---- i direction across the waves + patch of this wave's tile row: 8 tiles x (2 x 2) pixels x 32 couts ----
     float* sW = sPatch + wave * (32 * EPI_S);
     int* mtab = sMtab + wave * 32;
+    float yv[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int prow = lh * 16 + q;               // patch row = tl * 4 + a * 2 + bb
@@ -1664,8 +1675,11 @@ __global__ __launch_bounds__(256, 3) void conv_wino_kernel(const ConvParams p) {
         const int t = wave * 8 + tl;
         const float x0 = X[((0 * 2 + bb) * 32 + t) * 32 + lr], x1 = X[((1 * 2 + bb) * 32 + t) * 32 + lr];
         const float x2 = X[((2 * 2 + bb) * 32 + t) * 32 + lr], x3 = X[((3 * 2 + bb) * 32 + t) * 32 + lr];
-        sW[prow * EPI_S + lr] = a == 0 ? (x0 + x1) + x2 : (x1 - x2) - x3;
+        yv[q] = a == 0 ? (x0 + x1) + x2 : (x1 - x2) - x3;
     }
+    __syncthreads();                                // everybody has read X: the patches go on top of it
+#pragma unroll
+    for (int q = 0; q < 16; ++q) sW[(lh * 16 + q) * EPI_S + lr] = yv[q];
     if (lane < 32) {
         const int tl = lane >> 2, a = (lane >> 1) & 1, bb = lane & 1;
         const int t = wave * 8 + tl, ty = t / TWr, tx = t - ty * TWr;
