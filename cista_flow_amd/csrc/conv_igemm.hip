@@ -1443,7 +1443,8 @@ __host__ __device__ inline int wino_tall(int Ho, int Wo) {
     return tall < wide ? 1 : 0;
 }
 static constexpr int WG_KC = 8;                             // channels per chunk
-static constexpr int WG_RAW = 384 * 4;                      // floats per raw buffer: 360 16-byte slots, padded to whole wave-instructions
+static constexpr int WG_PLANE = 192;                        // cells per channel-quad plane of a raw buffer (180 live)
+static constexpr int WG_RAW = 2 * WG_PLANE * 4;             // floats per raw buffer: two planes of 16-byte slots = 6 wave-instructions
 static constexpr int WG_UV = 16 * 32 * WG_KC;               // floats per U / V buffer (4096)
 
 #ifndef WG_ABL
@@ -1459,17 +1460,17 @@ __global__ __launch_bounds__(256, 4) void conv_wino_kernel(const ConvParams p) {
     // pass then tracks the LDS-DMA writes per scope and puts s_waitcnt vmcnt(0) in front of the first ds_read that follows a
     // DMA issue -- which serialises the prefetch of chunk k+1 with the transform of chunk k.  Without scopes the DMA hand-off
     // is left to the explicit vmcnt waits + barriers below (as in conv_dma_kernel).
-    //   sV    [16 pos][32 tiles][8 k]   transformed input of the current chunk   } after the loop: the cross-wave exchange
-    //   sRaw  [2][WG_RAW]               raw patches (LDS-DMA ring of two)        } X[4][2][32][32], then the epilogue patches
-    //   sMtab                           row -> pixel tables of the epilogue patches
-    // 32.5 KB and <= 128 registers: four workgroups per CU, so that the transform / prologue / epilogue phases of one hide
-    // behind the MFMAs of the others.  U never enters LDS: wave w owns positions (w, 0..3), nobody else reads their weights,
-    // so each lane fetches its own MFMA B fragments (16 bytes, L2 hits) straight into registers while it transforms.
-    constexpr int WG_A = WG_UV + 2 * WG_RAW > 4 * 2 * 32 * 32 ? WG_UV + 2 * WG_RAW : 4 * 2 * 32 * 32;
-    static_assert(4 * 32 * EPI_S <= WG_A, "the epilogue patches overlay the exchange buffer");
+    //   sRaw  [2][2 channel quads][192 cells]   raw patches of the current / next chunk (LDS-DMA ring of two), 12 KB
+    //   after the loop: the cross-wave exchange X[4][2][32][32] (32 KB), then the epilogue patches; sMtab = their row -> pixel tables
+    // No V buffer: wave w owns positions (w, 0..3), i.e. row w of B^T d B, which needs two of the four patch rows of each tile;
+    // lane (tile lr, channel quad lh) reads those 2 x 4 pixels (4 channels each, ds_read_b128) and computes exactly the 16 values
+    // it feeds to its MFMAs as A operands -- the four waves together do each (tile, channel) transform once, nothing is written
+    // back to LDS, and one barrier per chunk (the raw hand-off) is left.  U never enters LDS either: nobody else reads a wave's
+    // weights, so each lane fetches its own B fragments (16 bytes, L2 hits) straight into registers.
+    constexpr int WG_A = 4 * 2 * 32 * 32;
+    static_assert(2 * WG_RAW <= WG_A && 4 * 32 * EPI_S <= WG_A, "raw ring and epilogue patches overlay the exchange buffer");
     __shared__ __attribute__((aligned(16))) float smem[WG_A + 4 * 32];
-    float* const sV = smem;
-    float* const sRaw = sV + WG_UV;
+    float* const sRaw = smem;
     float* const sPatch = smem;
     int* const sMtab = reinterpret_cast<int*>(smem + WG_A);
 
@@ -1498,20 +1499,20 @@ __global__ __launch_bounds__(256, 4) void conv_wino_kernel(const ConvParams p) {
     const int oy0 = (reg / nrx) * RH, ox0 = (reg % nrx) * RW;
     const int n0 = nblk * 32;
 
-    // ---- raw patch DMA slots: slot s -> patch cell s >> 1, channel quad s & 1.  Cells of a patch row are stored even columns
-    // first, then odd columns (cell = py * PC + (px >> 1) + (px & 1) * PC/2): the four tiles a 32-lane group reads at once
-    // (columns 2 tx + j) are then neighbours, 8 consecutive 16-byte slots = all 32 banks, instead of two tiles per bank ----
+    // ---- raw patch DMA slots: slot s -> channel quad s / 192, patch cell s % 192 (180 live).  Cells of a patch row are stored
+    // even columns first, then odd columns (cell = py * PC + (px >> 1) + (px & 1) * PC/2), so that the tiles of a tile row read
+    // neighbouring 16-byte slots of their quad's plane ----
     int a_pix[2];
     unsigned a_q[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int sl = tid + 256 * j;
-        const int cell = sl >> 1;
-        a_q[j] = (unsigned)(sl & 1) * 16u;
+        const int quad = sl >= WG_PLANE, cell = sl - quad * WG_PLANE;
+        a_q[j] = (unsigned)quad * 16u;
         const int py = cell / PC, pc = cell - py * PC;
         const int px = pc < PCh ? 2 * pc : 2 * (pc - PCh) + 1;
         int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
-        bool ok = sl < 2 * WG_PIX && iy <= p.Hin && ix <= p.Win;      // beyond the halo of the last row / column: unused
+        bool ok = sl < 2 * WG_PLANE && cell < WG_PIX && iy <= p.Hin && ix <= p.Win;      // beyond the halo of the last row / column: unused
         if (p.pad_mode == 1) {
             iy = reflect_idx(iy, p.Hin);
             ix = reflect_idx(ix, p.Win);
@@ -1533,7 +1534,7 @@ __global__ __launch_bounds__(256, 4) void conv_wino_kernel(const ConvParams p) {
         float* rbase = sRaw + buf * WG_RAW;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            if (256 * j + 64 * wave < 2 * WG_PIX) {        // wave-uniform: this wave-instruction covers live slots
+            if (256 * j + 64 * wave < 2 * WG_PLANE) {      // wave-uniform: this wave-instruction covers live slots
                 const unsigned off = a_pix[j] < 0 ? BUF_OOB : (unsigned)a_pix[j] * ld4 + a_q[j];
                 dma16_to_lds(rs, rbase + (256 * j + 64 * wave) * 4, off, so);
             }
@@ -1557,28 +1558,26 @@ __global__ __launch_bounds__(256, 4) void conv_wino_kernel(const ConvParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-    // transform mapping: tile t = wave * 8 + (lane >> 3) = (ty, tx) of the region, channel lane & 7
-    const int tcol = lane >> 3, tc = lane & 7;
-    const int tt = wave * 8 + tcol, tty = tt / TWr, ttx = tt - tty * TWr;
-    const int rsrc0 = (2 * tty * PC + ttx) * WG_KC + tc;                                // patch cell of pixel (2 ty, 2 tx), channel tc
-    const int vdst = ((wave * 8 + tcol) * WG_KC) + ((((tc >> 2) ^ (wave & 1)) << 2) | (tc & 3));   // + pos * 32 * 8
-    // fragment addresses (floats): row lr of position (wave, j), k quad lh (swizzled by (lr >> 3) & 1)
+    // lane (lr, lh): tile lr = (ty, tx) of the region, channel quad lh; its patch rows: ra, rb of {0,2} {1,2} {1,2} {1,3} for wave 0..3
     const int lr = lane & 31, lh = lane >> 5;
-    const int frag = lr * WG_KC + ((lh ^ ((lr >> 3) & 1)) << 2);
-    const unsigned uoff = (unsigned)((wave * 4) * 256 + frag) * 4u;                     // + j KiB: position (wave, j) of a chunk's U block
+    const int tty = lr / TWr, ttx = lr - tty * TWr;
+    const int ra = wave == 0 ? 0 : 1, rb = wave == 0 ? 2 : wave == 3 ? 3 : 2;
+    const int cell0 = 2 * tty * PC + ttx;                                             // cell of patch pixel (2 ty, 2 tx)
+    const int rd_a = (lh * WG_PLANE + cell0 + ra * PC) * 4, rd_b = (lh * WG_PLANE + cell0 + rb * PC) * 4;   // floats; + column cell * 4
+    const unsigned uoff = (unsigned)((wave * 4) * 256 + lr * WG_KC + ((lh ^ ((lr >> 3) & 1)) << 2)) * 4u;  // + j KiB: position (wave, j) of a chunk's U block
 
     auto load_u = [&](int chunk, f32x4 (&dst)[4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) dst[j] = buf_load4(u_rsrc, uoff + 1024u * j, (unsigned)chunk * (WG_UV * 4u));
     };
-    // one chunk: hand-off of raw(k); U(k) into registers, then the LDS-DMA of raw(k+1); transform; 16 MFMAs
+    // one chunk: hand-off of raw(k); U(k) into registers, then the LDS-DMA of raw(k+1); this wave's row of the transform; 16 MFMAs
     f32x4 bu[4] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}};
     auto chunk_step = [&](int k) __attribute__((always_inline)) {
 #ifdef CF_STAMP
         const long long t0 = __builtin_readcyclecounter();
 #endif
         wait_vmcnt0();
-        raw_barrier();                              // raw(k) has landed for everybody; iteration k-1 is finished everywhere
+        raw_barrier();                              // raw(k) has landed for everybody; everybody has read raw(k-1)
 #ifdef CF_STAMP
         const long long t1 = __builtin_readcyclecounter();
 #endif
@@ -1590,52 +1589,38 @@ __global__ __launch_bounds__(256, 4) void conv_wino_kernel(const ConvParams p) {
         if (k + 1 < nchunk) issue_raw((k + 1) & 1);
 #endif
         __builtin_amdgcn_sched_barrier(0);
-        // ---- input transform V = B^T d B ----
+        f32x4 af[4];
 #if !(WG_ABL & 1)
         {
-            const float* r = sRaw + (k & 1) * WG_RAW + rsrc0;
-            float d[4][4];
+            const float* r = sRaw + (k & 1) * WG_RAW;
+            f32x4 t[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) d[i][j] = r[(i * PC + (j >> 1) + (j & 1) * PCh) * WG_KC];
-            float t[4][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                t[0][j] = d[0][j] - d[2][j];
-                t[1][j] = d[1][j] + d[2][j];
-                t[2][j] = d[2][j] - d[1][j];
-                t[3][j] = d[1][j] - d[3][j];
+            for (int c = 0; c < 4; ++c) {
+                const int col = ((c >> 1) + (c & 1) * PCh) * 4;
+                const f32x4 da = *reinterpret_cast<const f32x4*>(r + rd_a + col);
+                const f32x4 db = *reinterpret_cast<const f32x4*>(r + rd_b + col);
+                // row `wave` of B^T d: d0 - d2, d1 + d2, d2 - d1, d1 - d3 (wave-uniform choice)
+                t[c] = wave == 1 ? da + db : wave == 2 ? db - da : da - db;
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                sV[(i * 4 + 0) * 256 + vdst] = t[i][0] - t[i][2];
-                sV[(i * 4 + 1) * 256 + vdst] = t[i][1] + t[i][2];
-                sV[(i * 4 + 2) * 256 + vdst] = t[i][2] - t[i][1];
-                sV[(i * 4 + 3) * 256 + vdst] = t[i][1] - t[i][3];
-            }
+            af[0] = t[0] - t[2];
+            af[1] = t[1] + t[2];
+            af[2] = t[2] - t[1];
+            af[3] = t[1] - t[3];
         }
+#else
+        for (int j = 0; j < 4; ++j) af[j] = bu[j];
 #endif
-        wait_lgkm0();                               // this wave's V writes are done ...
 #ifdef CF_STAMP
+        wait_lgkm0();
         const long long t2 = __builtin_readcyclecounter();
-#endif
-        raw_barrier();                              // ... and everybody's (NOT __syncthreads: it would drain the prefetch)
-#ifdef CF_STAMP
         st_wait += t1 - t0;
-        st_bar += __builtin_readcyclecounter() - t2;
         st_issue += t2 - t1;
 #endif
         // ---- 16 MFMAs: positions (wave, 0..3) ----
-        {
-            f32x4 af[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const f32x4*>(sV + (wave * 4 + j) * 256 + frag);
+        for (int s2 = 0; s2 < 4; ++s2)
 #pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][s2], bu[j][s2], acc[j], 0, 0, 0);
-        }
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][s2], bu[j][s2], acc[j], 0, 0, 0);
     };
 
     issue_raw(0);
@@ -1654,9 +1639,9 @@ __global__ __launch_bounds__(256, 4) void conv_wino_kernel(const ConvParams p) {
         return;
     }
 #endif
-    __syncthreads();                                // every wave is done with V before it becomes the exchange buffer
+    __syncthreads();                                // every wave is done with the raw ring before it becomes the exchange buffer
     // ---- output transform, j direction (in registers): R[0] = M0 + M1 + M2, R[1] = M1 - M2 - M3 ----
-    float* X = smem;                                // X[i = wave][bcol][tile 32][cout 32], over V + raw
+    float* X = smem;                                // X[i = wave][bcol][tile 32][cout 32], over the raw ring
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int trow = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -1700,6 +1685,212 @@ __global__ __launch_bounds__(256, 4) void conv_wino_kernel(const ConvParams p) {
         q[7] = dr > 0 ? ((__builtin_readcyclecounter() - t_begin) * 100) / dr : 0;
     }
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The same Winograd kernel with eight waves per workgroup: 32 tiles x 64 output channels, K in chunks of 16 channels.
+// Everything that is not an MFMA (raw-patch DMA, input transform, U loads) costs SIMD issue time that the matrix pipe does
+// not hide (ablations: the costs add up), and the transform + raw patch of a region serve every output channel: with 64
+// channels per workgroup they are paid once per 32 MFMAs of a wave instead of once per 16.  Wave w = (i = w & 3, h = w >> 2)
+// owns positions (i, 0..3) of output channels [n0 + 32 h, n0 + 32 h + 32); a lane transforms one (tile, channel) of the
+// 32 x 16 chunk.  Needs cout % 64 == 0 and every channel segment % 16 == 0; the U layout is the four-wave kernel's.
+static constexpr int W8_KC = 16;
+static constexpr int W8_RAW = 768 * 4;                      // floats per raw buffer: 720 16-byte slots, padded to whole wave-instructions
+static constexpr int W8_V = 16 * 32 * W8_KC;                // floats of V (8192)
+
+__global__ __launch_bounds__(512, 4) void conv_wino8_kernel(const ConvParams p) {
+    //   sV    [16 pos][32 tiles][16 k]  (32 KB)   } after the loop: the exchange X[8 waves][2][32][32] (64 KB), then the
+    //   sRaw  [2][W8_RAW]               (24 KB)   } eight epilogue patches
+    // one __shared__ object: see conv_wino_kernel
+    constexpr int W8_A = 8 * 2 * 32 * 32;
+    static_assert(W8_V + 2 * W8_RAW <= W8_A && 8 * 32 * EPI_S <= W8_A, "loop buffers and patches overlay the exchange buffer");
+    __shared__ __attribute__((aligned(16))) float smem[W8_A + 8 * 32];
+    float* const sV = smem;
+    float* const sRaw = sV + W8_V;
+    float* const sPatch = smem;
+    int* const sMtab = reinterpret_cast<int*>(smem + W8_A);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave & 3, wh = wave >> 2;
+    const int Ho = p.Ho, Wo = p.Wo;
+    const int tall = wino_tall(Ho, Wo);
+    const int TWr = tall ? 4 : 8;
+    const int RH = tall ? 16 : 8, RW = tall ? 8 : 16;
+    const int PC = RW + 2, PCh = PC >> 1;
+    const int nrx = (Wo + RW - 1) / RW, nry = (Ho + RH - 1) / RH;
+    const int nreg = nrx * nry;
+    const int nt = p.cout / 64;
+    int tile_id = blockIdx.x;
+    if (p.sched == 1) {
+        const int nwg = gridDim.x;
+        const int q8 = nwg >> 3, r8 = nwg & 7;
+        const int xcd = tile_id & 7;
+        tile_id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (tile_id >> 3);
+    }
+    const int nblk = tile_id % nt;
+    const int rest = tile_id / nt;
+    const int reg = rest % nreg;
+    const int b = rest / nreg;
+    const int oy0 = (reg / nrx) * RH, ox0 = (reg % nrx) * RW;
+    const int n0 = nblk * 64 + wh * 32;
+
+    // raw patch DMA slots: slot s -> patch cell s >> 2 (even columns first, as in conv_wino_kernel), channel quad s & 3
+    int a_pix[2];
+    unsigned a_q[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int sl = tid + 512 * j;
+        const int cell = sl >> 2;
+        a_q[j] = (unsigned)(sl & 3) * 16u;
+        const int py = cell / PC, pc = cell - py * PC;
+        const int px = pc < PCh ? 2 * pc : 2 * (pc - PCh) + 1;
+        int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+        bool ok = sl < 4 * WG_PIX && iy <= p.Hin && ix <= p.Win;
+        if (p.pad_mode == 1) {
+            iy = reflect_idx(iy, p.Hin);
+            ix = reflect_idx(ix, p.Win);
+        } else {
+            ok = ok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
+        }
+        a_pix[j] = ok ? iy * p.Win + ix : -1;
+    }
+    const int nchunk = p.cin_pad / W8_KC;
+    const __amdgpu_buffer_rsrc_t u_rsrc =
+        make_rsrc(p.w_wino + (long)wgroup(p, b) * p.wino_gs + (long)(nblk * 2 + wh) * (p.cin_pad / WG_KC) * WG_UV);
+
+    int it_seg = 0, it_cs = 0;
+    const float* seg_base = p.in[0] + (long)b * p.seg_bs[0];
+    int seg_ld = p.seg_ld[0], seg_cn = p.seg_c[0];
+    auto issue_raw = [&](int buf) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(seg_base);
+        const unsigned ld4 = (unsigned)seg_ld * 4u, so = (unsigned)it_cs * 4u;
+        float* rbase = sRaw + buf * W8_RAW;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (512 * j + 64 * wave < 4 * WG_PIX) {        // wave-uniform: this wave-instruction covers live slots
+                const unsigned off = a_pix[j] < 0 ? BUF_OOB : (unsigned)a_pix[j] * ld4 + a_q[j];
+                dma16_to_lds(rs, rbase + (512 * j + 64 * wave) * 4, off, so);
+            }
+        }
+        it_cs += W8_KC;
+        if (it_cs >= seg_cn) {
+            it_cs = 0;
+            ++it_seg;
+            if (it_seg < p.nseg) {
+                seg_base = sel3(p.in, it_seg) + (long)b * (it_seg == 1 ? p.seg_bs[1] : p.seg_bs[2]);
+                seg_ld = it_seg == 1 ? p.seg_ld[1] : p.seg_ld[2];
+                seg_cn = it_seg == 1 ? p.seg_c[1] : p.seg_c[2];
+            }
+        }
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    // transform mapping: tile t = wave * 4 + (lane >> 4), channel lane & 15
+    const int tl4 = lane >> 4, tc = lane & 15;
+    const int tt = wave * 4 + tl4, tty = tt / TWr, ttx = tt - tty * TWr;
+    const int rsrc0 = (2 * tty * PC + ttx) * W8_KC + tc;
+    const int vdst = tt * W8_KC + ((((tc >> 2) ^ ((tt >> 2) & 3)) << 2) | (tc & 3));     // + pos * 32 * 16
+    // fragments: A = row lr of V, logical k quad 2 e + lh, stored at quad ^ ((lr >> 2) & 3) (conflict-free ds_read_b128);
+    // B = U block (8-channel chunk 2 k + e, position (wi, j)): row lr, quad lh ^ ((lr >> 3) & 1) as launch_wino_weights wrote it
+    const int lr = lane & 31, lh = lane >> 5;
+    const int fragA0 = lr * W8_KC + (((0 + lh) ^ ((lr >> 2) & 3)) << 2);
+    const int fragA1 = lr * W8_KC + (((2 + lh) ^ ((lr >> 2) & 3)) << 2);
+    const unsigned uoff0 = (unsigned)((wi * 4) * 256 + lr * WG_KC + ((lh ^ ((lr >> 3) & 1)) << 2)) * 4u;
+    const unsigned uoff1 = uoff0 + (unsigned)WG_UV * 4u;
+
+    f32x4 bu[2][4];
+    auto chunk_step = [&](int k) __attribute__((always_inline)) {
+        wait_vmcnt0();
+        raw_barrier();                              // raw(k) has landed for everybody; iteration k-1 is finished everywhere
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bu[0][j] = buf_load4(u_rsrc, uoff0 + 1024u * j, (unsigned)k * (2u * WG_UV * 4u));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bu[1][j] = buf_load4(u_rsrc, uoff1 + 1024u * j, (unsigned)k * (2u * WG_UV * 4u));
+        __builtin_amdgcn_sched_barrier(0);          // U(k) before raw(k+1) in issue order: the MFMAs then wait for U(k) only
+        if (k + 1 < nchunk) issue_raw((k + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const float* r = sRaw + (k & 1) * W8_RAW + rsrc0;
+            float d[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[i][j] = r[(i * PC + (j >> 1) + (j & 1) * PCh) * W8_KC];
+            float t[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                t[0][j] = d[0][j] - d[2][j];
+                t[1][j] = d[1][j] + d[2][j];
+                t[2][j] = d[2][j] - d[1][j];
+                t[3][j] = d[1][j] - d[3][j];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sV[(i * 4 + 0) * 512 + vdst] = t[i][0] - t[i][2];
+                sV[(i * 4 + 1) * 512 + vdst] = t[i][1] + t[i][2];
+                sV[(i * 4 + 2) * 512 + vdst] = t[i][2] - t[i][1];
+                sV[(i * 4 + 3) * 512 + vdst] = t[i][1] - t[i][3];
+            }
+        }
+        wait_lgkm0();
+        raw_barrier();                              // V is complete (NOT __syncthreads: it would drain the prefetch)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            f32x4 af[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const f32x4*>(sV + (wi * 4 + j) * 512 + (e ? fragA1 : fragA0));
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][s2], bu[e][j][s2], acc[j], 0, 0, 0);
+        }
+    };
+    issue_raw(0);
+    for (int k = 0; k < nchunk; ++k) chunk_step(k);
+
+    __syncthreads();                                // every wave is done with V before it becomes the exchange buffer
+    float* X = smem;                                // X[wave][bcol][tile 32][cout 32]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int trow = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        X[((wave * 2 + 0) * 32 + trow) * 32 + lr] = (acc[0][r] + acc[1][r]) + acc[2][r];
+        X[((wave * 2 + 1) * 32 + trow) * 32 + lr] = (acc[1][r] - acc[2][r]) - acc[3][r];
+    }
+    __syncthreads();
+    float* sW = sPatch + wave * (32 * EPI_S);
+    int* mtab = sMtab + wave * 32;
+    float yv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int prow = lh * 16 + q;               // patch row = tl * 4 + a * 2 + bb
+        const int tl = prow >> 2, a = (prow >> 1) & 1, bb = prow & 1;
+        const int t = wi * 8 + tl;
+        const float* Xh = X + wh * (4 * 2 * 32 * 32);
+        const float x0 = Xh[((0 * 2 + bb) * 32 + t) * 32 + lr], x1 = Xh[((1 * 2 + bb) * 32 + t) * 32 + lr];
+        const float x2 = Xh[((2 * 2 + bb) * 32 + t) * 32 + lr], x3 = Xh[((3 * 2 + bb) * 32 + t) * 32 + lr];
+        yv[q] = a == 0 ? (x0 + x1) + x2 : (x1 - x2) - x3;
+    }
+    __syncthreads();                                // everybody has read X: the patches go on top of it
+#pragma unroll
+    for (int q = 0; q < 16; ++q) sW[(lh * 16 + q) * EPI_S + lr] = yv[q];
+    if (lane < 32) {
+        const int tl = lane >> 2, a = (lane >> 1) & 1, bb = lane & 1;
+        const int t = wi * 8 + tl, ty = t / TWr, tx = t - ty * TWr;
+        const int oy = oy0 + 2 * ty + a, ox = ox0 + 2 * tx + bb;
+        mtab[lane] = (oy < Ho && ox < Wo) ? oy * Wo + ox : -1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    patch_tail(p, sW, b, 0, n0, lane, Ho * Wo, 0, 4, 1, 0, mtab);
+    if (p.st_partial) patch_stats(p, sW, b, 0, n0, lane, Ho * Wo, mtab, reg * 4 + wi, nreg * 4);
 }
 
 // U = G g G^T of a packed direct matrix w [rows][tap][cin_pad] (BatchNorm folds, stacking, interleaving already applied),
@@ -1746,7 +1937,7 @@ static int wino_regions(int Ho, int Wo) {
 
 // statistics partials a convolution with st_partial writes per image: one per 32-pixel patch, or per Winograd tile row
 int conv_stats_chunks(const ConvParams& p, int tile) {
-    if (tile == 40) return wino_regions(p.Ho, p.Wo) * 4;
+    if (tile == 40 || tile == 41) return wino_regions(p.Ho, p.Wo) * 4;
     return (p.Ho * p.Wo + 31) / 32;
 }
 
@@ -1766,6 +1957,22 @@ static hipError_t launch_wino(const ConvParams& p, int batch, hipStream_t s) {
     if (wgs <= 0 || wgs >= 0x7FFFFFFFL) return hipErrorInvalidValue;
     g_last_launch.threads = wgs * 256;
     hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)wgs), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+
+static bool wino8_ok(const ConvParams& p) {
+    if (!wino_ok(p) || p.cout % 64 || p.cin_pad % W8_KC) return false;
+    for (int i = 0; i < p.nseg; ++i)
+        if (p.seg_c[i] % W8_KC) return false;
+    return true;
+}
+
+static hipError_t launch_wino8(const ConvParams& p, int batch, hipStream_t s) {
+    if (!wino8_ok(p)) return hipErrorInvalidValue;
+    const long wgs = (long)wino_regions(p.Ho, p.Wo) * (p.cout / 64) * batch;
+    if (wgs <= 0 || wgs >= 0x7FFFFFFFL) return hipErrorInvalidValue;
+    g_last_launch.threads = wgs * 512;
+    hipLaunchKernelGGL(conv_wino8_kernel, dim3((unsigned)wgs), dim3(512), 0, s, p);
     return hipGetLastError();
 }
 
@@ -2012,6 +2219,7 @@ const char* conv_tile_name(int tile) {
         case 33: return "conv_dma_kernel<128,64,2,2,1,16,nbuf4>";
         case 34: return "conv_dma_kernel<32,96,1,1,4,8>";
         case 40: return "conv_wino_kernel";
+        case 41: return "conv_wino8_kernel";
         default: return "?";
     }
 }
@@ -2104,7 +2312,7 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
     if (tile == 0 && wino_ok(p)) {
         const long tb = p.tile_batch > 0 ? p.tile_batch : batch;
         const long wg = (long)wino_regions(p.Ho, p.Wo) * ((p.cout + 31) / 32) * tb;
-        if (wg >= 128) tile = 40;
+        if (wg >= 128) tile = 40;      // (the eight-wave tile 41 measured -3..+6 % per layer, -1.4 % on the whole step: explicit only)
     }
     if (tile == 0) {
         // Pick the largest tile that still yields >= ~2 workgroups per CU (measured with tools/conv_bench.py on
@@ -2198,6 +2406,7 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
         case 33: return launch_dma<128, 64, 2, 2, 1, 16, 4>(p, batch, s);
         case 34: return launch_dma<32, 96, 1, 1, 4, 8>(p, batch, s);
         case 40: return launch_wino(p, batch, s);
+        case 41: return launch_wino8(p, batch, s);
         default: return hipErrorInvalidValue;
     }
 }

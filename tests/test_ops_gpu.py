@@ -140,6 +140,7 @@ STATS_CASES = [
     (64, 96, 3, 3, 2, 1, 0, 0, 96, 128),     # ... as the launcher picks it for the 96-channel stage
     (64, 64, 3, 3, 1, 1, 0, 40, 48, 64),     # Winograd tile: one partial per tile row of an 8 x 16 region
     (96, 96, 3, 3, 1, 1, 0, 40, 21, 37),     # ... ragged regions
+    (64, 128, 3, 3, 1, 1, 0, 41, 21, 37),    # eight-wave Winograd tile
 ]
 
 
@@ -191,7 +192,8 @@ def test_conv_nhwc(gpu, case):
 
 
 WINO_CASES = [(64, 64, 1, 20, 28, 0), (128, 64, 0, 20, 28, 1), (16, 32, 1, 13, 21, 2), (48, 96, 0, 24, 40, 3),
-              (256, 126, 0, 24, 32, 1), (192, 256, 1, 17, 33, 0), (64, 128, 1, 90, 120, 0)]
+              (256, 126, 0, 24, 32, 1), (192, 256, 1, 17, 33, 0), (64, 128, 1, 90, 120, 0), (48, 128, 1, 23, 30, 2),
+              (256, 128, 0, 26, 19, 3)]
 
 
 @pytest.mark.parametrize("case", WINO_CASES)
@@ -212,6 +214,10 @@ def test_conv_winograd(gpu, case):
     assert got.shape == ref.shape
     assert (got - ref).abs().max().item() < 1e-4
     assert (got - direct).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    if Cout % 64 == 0 and Cin % 16 == 0:       # the eight-wave kernel (tile 41): 64 output channels x 16-channel chunks
+        got8 = run_conv(gpu, x, w, b, 1, 1, 1, pad_mode, 0, epi, 41, H, W)
+        assert (got8 - ref).abs().max().item() < 1e-4
+        assert (got8 - direct).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
 @pytest.mark.parametrize("epi", [1, 2, 3])
