@@ -1444,7 +1444,7 @@ __host__ __device__ inline int wino_tall(int Ho, int Wo) {
 }
 static constexpr int WG_KC = 8;                             // channels per chunk
 static constexpr int WG_PLANE = 192;                        // cells per channel-quad plane of a raw buffer (180 live)
-static constexpr int WG_RAW = 2 * WG_PLANE * 4;             // floats per raw buffer: two planes of 16-byte slots = 6 wave-instructions
+static constexpr int WG_RAW = 512 * 4;                      // floats per raw buffer: two planes of 16-byte slots, padded to 2 x 256 slots
 static constexpr int WG_UV = 16 * 32 * WG_KC;               // floats per U / V buffer (4096)
 
 #ifndef WG_ABL
@@ -1507,12 +1507,12 @@ __global__ __launch_bounds__(256, 4) void conv_wino_kernel(const ConvParams p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int sl = tid + 256 * j;
-        const int quad = sl >= WG_PLANE, cell = sl - quad * WG_PLANE;
-        a_q[j] = (unsigned)quad * 16u;
+        const int quad = sl / WG_PLANE, cell = sl - quad * WG_PLANE;      // quad 2: the dead slots 384..511
+        a_q[j] = (unsigned)(quad & 1) * 16u;
         const int py = cell / PC, pc = cell - py * PC;
         const int px = pc < PCh ? 2 * pc : 2 * (pc - PCh) + 1;
         int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
-        bool ok = sl < 2 * WG_PLANE && cell < WG_PIX && iy <= p.Hin && ix <= p.Win;      // beyond the halo of the last row / column: unused
+        bool ok = quad < 2 && cell < WG_PIX && iy <= p.Hin && ix <= p.Win;      // beyond the halo of the last row / column: unused
         if (p.pad_mode == 1) {
             iy = reflect_idx(iy, p.Hin);
             ix = reflect_idx(ix, p.Win);
@@ -1528,16 +1528,17 @@ __global__ __launch_bounds__(256, 4) void conv_wino_kernel(const ConvParams p) {
     int it_seg = 0, it_cs = 0;
     const float* seg_base = p.in[0] + (long)b * p.seg_bs[0];
     int seg_ld = p.seg_ld[0], seg_cn = p.seg_c[0];
-    auto issue_raw = [&](int buf) __attribute__((always_inline)) {
+    // Every wave issues exactly two DMA instructions per chunk, unconditionally (dead slots and the chunk past the end fetch
+    // out of range = zeros into unused LDS): with a fixed count the compiler's s_waitcnt vmcnt before each position's MFMAs
+    // waits for that position's U registers only, not for the raw patch of the next chunk behind them in the queue.
+    auto issue_raw = [&](int buf, bool live) __attribute__((always_inline)) {
         const __amdgpu_buffer_rsrc_t rs = make_rsrc(seg_base);
         const unsigned ld4 = (unsigned)seg_ld * 4u, so = (unsigned)it_cs * 4u;
         float* rbase = sRaw + buf * WG_RAW;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            if (256 * j + 64 * wave < 2 * WG_PLANE) {      // wave-uniform: this wave-instruction covers live slots
-                const unsigned off = a_pix[j] < 0 ? BUF_OOB : (unsigned)a_pix[j] * ld4 + a_q[j];
-                dma16_to_lds(rs, rbase + (256 * j + 64 * wave) * 4, off, so);
-            }
+            const unsigned off = (a_pix[j] < 0 || !live) ? BUF_OOB : (unsigned)a_pix[j] * ld4 + a_q[j];
+            dma16_to_lds(rs, rbase + (256 * j + 64 * wave) * 4, off, so);
         }
         // advance to the next chunk
         it_cs += WG_KC;
@@ -1562,6 +1563,7 @@ __global__ __launch_bounds__(256, 4) void conv_wino_kernel(const ConvParams p) {
     const int lr = lane & 31, lh = lane >> 5;
     const int tty = lr / TWr, ttx = lr - tty * TWr;
     const int ra = wave == 0 ? 0 : 1, rb = wave == 0 ? 2 : wave == 3 ? 3 : 2;
+    const float sgn = wave == 1 ? 1.f : -1.f;
     const int cell0 = 2 * tty * PC + ttx;                                             // cell of patch pixel (2 ty, 2 tx)
     const int rd_a = (lh * WG_PLANE + cell0 + ra * PC) * 4, rd_b = (lh * WG_PLANE + cell0 + rb * PC) * 4;   // floats; + column cell * 4
     const unsigned uoff = (unsigned)((wave * 4) * 256 + lr * WG_KC + ((lh ^ ((lr >> 3) & 1)) << 2)) * 4u;  // + j KiB: position (wave, j) of a chunk's U block
@@ -1570,38 +1572,40 @@ __global__ __launch_bounds__(256, 4) void conv_wino_kernel(const ConvParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) dst[j] = buf_load4(u_rsrc, uoff + 1024u * j, (unsigned)chunk * (WG_UV * 4u));
     };
-    // one chunk: hand-off of raw(k); U(k) into registers, then the LDS-DMA of raw(k+1); this wave's row of the transform; 16 MFMAs
+    // one chunk: hand-off of raw(k); LDS-DMA of raw(k+1); this wave's row of the transform; 16 MFMAs, position by position, each
+    // position's U registers refilled for chunk k+1 as soon as its four MFMAs are issued (a whole chunk of lead, no second buffer)
     f32x4 bu[4] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}};
     auto chunk_step = [&](int k) __attribute__((always_inline)) {
 #ifdef CF_STAMP
         const long long t0 = __builtin_readcyclecounter();
 #endif
-        wait_vmcnt0();
+        // in flight, oldest first: the two raw(k) pieces, then the four U(k) loads -- raw(k) has landed once at most four are outstanding
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         raw_barrier();                              // raw(k) has landed for everybody; everybody has read raw(k-1)
 #ifdef CF_STAMP
         const long long t1 = __builtin_readcyclecounter();
 #endif
-#if !(WG_ABL & 2)
-        load_u(k, bu);
-#endif
-        __builtin_amdgcn_sched_barrier(0);          // U(k) before raw(k+1) in issue order: the MFMAs then wait for U(k) only
+        const bool more = k + 1 < nchunk;
 #if !(WG_ABL & 8)
-        if (k + 1 < nchunk) issue_raw((k + 1) & 1);
+        issue_raw((k + 1) & 1, more);
 #endif
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);          // raw(k+1) before U(k+1) in issue order: the vmcnt(4) above counts on it
         f32x4 af[4];
 #if !(WG_ABL & 1)
         {
             const float* r = sRaw + (k & 1) * WG_RAW;
-            f32x4 t[4];
+            f32x4 da[4], db[4], t[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int col = ((c >> 1) + (c & 1) * PCh) * 4;
-                const f32x4 da = *reinterpret_cast<const f32x4*>(r + rd_a + col);
-                const f32x4 db = *reinterpret_cast<const f32x4*>(r + rd_b + col);
-                // row `wave` of B^T d: d0 - d2, d1 + d2, d2 - d1, d1 - d3 (wave-uniform choice)
-                t[c] = wave == 1 ? da + db : wave == 2 ? db - da : da - db;
+                da[c] = *reinterpret_cast<const f32x4*>(r + rd_a + col);
+                db[c] = *reinterpret_cast<const f32x4*>(r + rd_b + col);
             }
+            // row `wave` of B^T d: d0 - d2, d1 + d2, -(d2 - d1), d1 - d3  =  da + sgn * db (exact: sgn = +-1; row 2 negated, as its U is)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[c][e] = __builtin_fmaf(sgn, db[c][e], da[c][e]);
             af[0] = t[0] - t[2];
             af[1] = t[1] + t[2];
             af[2] = t[2] - t[1];
@@ -1617,13 +1621,25 @@ __global__ __launch_bounds__(256, 4) void conv_wino_kernel(const ConvParams p) {
         st_issue += t2 - t1;
 #endif
         // ---- 16 MFMAs: positions (wave, 0..3) ----
+        const unsigned u_next = (unsigned)(more ? k + 1 : k) * (WG_UV * 4u);      // past the end: a harmless re-load
 #pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2)
+        for (int j = 0; j < 4; ++j) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][s2], bu[j][s2], acc[j], 0, 0, 0);
+            for (int s2 = 0; s2 < 4; ++s2) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][s2], bu[j][s2], acc[j], 0, 0, 0);
+#if !(WG_ABL & 2)
+            __builtin_amdgcn_sched_barrier(0);
+            bu[j] = buf_load4(u_rsrc, uoff + 1024u * j, u_next);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
     };
 
-    issue_raw(0);
+    issue_raw(0, true);
+    __builtin_amdgcn_sched_barrier(0);
+#if !(WG_ABL & 2)
+    load_u(0, bu);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
 #ifdef CF_STAMP
     const long long t_loop_begin = __builtin_readcyclecounter();
 #endif
@@ -1828,7 +1844,7 @@ __global__ __launch_bounds__(512, 4) void conv_wino8_kernel(const ConvParams p) 
             for (int j = 0; j < 4; ++j) {
                 t[0][j] = d[0][j] - d[2][j];
                 t[1][j] = d[1][j] + d[2][j];
-                t[2][j] = d[2][j] - d[1][j];
+                t[2][j] = d[1][j] - d[2][j];          // negated, as the stored U of row 2 is (launch_wino_weights)
                 t[3][j] = d[1][j] - d[3][j];
             }
 #pragma unroll
@@ -1918,7 +1934,9 @@ __global__ void wino_weight_kernel(const float* __restrict__ w, float* __restric
         for (int a = 0; a < 3; ++a)
             for (int bq = 0; bq < 3; ++bq)
                 acc += (double)G[i][a] * (double)w[(long)n * 9 * cin_pad + (long)(a * 3 + bq) * cin_pad + c] * (double)G[j][bq];
-        val = (float)acc;
+        // row i = 2 is stored NEGATED: the kernels compute -(row 2 of B^T d B) = (d1 - d2 ...), so that three of the four waves share
+        // one formula (a - b) and the fourth (a + b) differs by a scalar sign only; (-V)(-U) = V U exactly
+        val = i == 2 ? -(float)acc : (float)acc;
     }
     u[idx] = val;
 }
