@@ -120,6 +120,11 @@ def roofline_pass(model, step, B, dev, nprof):
             a["ms"] += r["ms"]; a["work"] += r["work"]; a["launches"] += r["launches"]
         return out
 
+    def executed(r):
+        """flops the matrix cores execute for a launch-site row: Winograd F(2x2,3x3) launches do 16 products per 2x2 outputs
+        instead of the 36 of the 3x3 convolution they compute, i.e. 4/9 of the algorithmic flops; every other kernel all of them"""
+        return r["work"] * (4.0 / 9.0 if r["kernel"].startswith("conv_wino") else 1.0)
+
     mf = agg(lambda r: r["class"] == "mfma")
     hb = agg(lambda r: r["class"] == "hbm")
     dom_name = max(mf, key=lambda k: mf[k]["ms"])
@@ -145,6 +150,7 @@ def roofline_pass(model, step, B, dev, nprof):
     def cls(sel):
         m_ms = sum(r["ms"] for r in rows if sel(r) and r["class"] == "mfma")
         m_w = sum(r["work"] for r in rows if sel(r) and r["class"] == "mfma")
+        m_x = sum(executed(r) for r in rows if sel(r) and r["class"] == "mfma")
         b_ms = sum(r["ms"] for r in rows if sel(r) and r["class"] == "hbm")
         b_w = sum(r["work"] for r in rows if sel(r) and r["class"] == "hbm")
         tot = m_ms + b_ms
@@ -152,7 +158,10 @@ def roofline_pass(model, step, B, dev, nprof):
         hfr = (b_w / (b_ms * 1e-3) / 1e12 / PEAK_HBM_TBS) if b_ms else None
         comb = ((m_ms * (mfr or 0) + b_ms * (hfr or 0)) / tot) if tot else None
         return {"ms_per_step": round(tot / nprof, 3), "mfma_ms_per_step": round(m_ms / nprof, 3), "hbm_ms_per_step": round(b_ms / nprof, 3),
-                "mfma_frac": None if mfr is None else round(mfr, 4), "hbm_frac": None if hfr is None else round(hfr, 4),
+                # mfma_frac prices ALGORITHMIC flops (can pass 1 where Winograd launches dominate); mfma_executed_frac the executed ones
+                "mfma_frac": None if mfr is None else round(mfr, 4),
+                "mfma_executed_frac": round(m_x / (m_ms * 1e-3) / 1e12 / mfma_peak(), 4) if m_ms else None,
+                "hbm_frac": None if hfr is None else round(hfr, 4),
                 "time_weighted_frac": None if comb is None else round(comb, 4)}
 
     return {
@@ -162,11 +171,14 @@ def roofline_pass(model, step, B, dev, nprof):
                 "chip), SAME launch grids as the timed step (half-batch CISTA chains kept, issued back to back)",
         # conv_wino_kernel = Winograd F(2x2,3x3): `achieved` prices the ALGORITHMIC flops of the 3x3 convolution (2*M*N*9*Cin, what
         # the reference executes); the matrix cores execute 16 products per 2x2 outputs instead of 36, i.e. 4/9 of that
-        "mfma_executed_tflops": round(ach * 4.0 / 9.0, 2) if dom_name == "conv_wino_kernel" else round(ach, 2),
+        "mfma_executed_tflops": round(ach * 4.0 / 9.0, 2) if dom_name.startswith("conv_wino") else round(ach, 2),
+        "mfma_executed_frac": round(ach * (4.0 / 9.0 if dom_name.startswith("conv_wino") else 1.0) / mfma_peak(), 4),
         "launches_per_step": dom["launches"] / nprof,
         "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
         "flops_per_launch": dom["work"] / dom["launches"],
-        "all_conv": {"achieved": round(mf_work / (mf_ms * 1e-3) / 1e12, 2), "ms_per_step": round(mf_ms / nprof, 3),
+        "all_conv": {"achieved": round(mf_work / (mf_ms * 1e-3) / 1e12, 2),
+                     "executed": round(sum(executed(r) for r in rows if r["class"] == "mfma") / (mf_ms * 1e-3) / 1e12, 2),
+                     "ms_per_step": round(mf_ms / nprof, 3),
                      "launches_per_step": sum(v["launches"] for v in mf.values()) / nprof, "gflop_per_step": round(mf_work / nprof / 1e9, 2)},
         "by_kernel": {k: {"ms_per_step": round(v["ms"] / nprof, 3), "tflops": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 2),
                           "launches_per_step": v["launches"] / nprof} for k, v in sorted(mf.items(), key=lambda kv: -kv[1]["ms"])},

@@ -1424,16 +1424,18 @@ void conv_dma_kernel(const ConvParams p) {
 // pixels) x 32 output channels, K = Cin in chunks of 8 channels:
 //   raw     the (10 x 18 pixel) x 8-channel input patch of a chunk, LDS-DMA'd straight from the NHWC tensor (reflect /
 //           zero padding resolved in the per-lane source offset; double buffered);
-//   V       = B^T d B for the 32 tiles, one (tile, channel) pair per thread (32 adds), written [pos][tile][8 k];
-//   U       = G g G^T, transformed ONCE at weight-pack time into [n-block][chunk][pos][32 n][8 k] blocks, so a chunk's
-//           16 KB arrive by linear LDS-DMA (double buffered);
-//   MFMA    wave w owns positions (w, 0..3) of the 4x4 grid: 4 accumulators [32 tiles x 32 couts], 16 x
-//           v_mfma_f32_32x32x2_f32 per chunk; the 16-byte fragment slots of V / U rows are XOR-swizzled by (row >> 3) & 1
-//           so that ds_read_b128 is conflict free;
+//   MFMA    wave w owns positions (w, 0..3) of the 4x4 grid = row w of B^T d B: 4 accumulators [32 tiles x 32 couts], 16 x
+//           v_mfma_f32_32x32x2_f32 per chunk;
+//   V       never stored: row w needs two of a tile's four patch rows, so lane (tile, channel quad) reads 2 x 4 pixels x 4
+//           channels (8 ds_read_b128 of the raw patch) and computes exactly its own 16 A operands in registers (32 VALU
+//           ops); the four waves together transform every (tile, channel) once; ONE barrier per chunk;
+//   U       = G g G^T, transformed ONCE at weight-pack time into [n-block][chunk][pos][32 n][8 k] blocks (row 2 negated,
+//           see wino_weight_kernel); nobody but wave w reads positions (w, .), so each lane loads its own B fragments from
+//           global memory (L2) into registers, one chunk ahead, position by position behind that position's MFMAs;
 //   tail    the A^T . A reduction is separable: along j inside the wave (registers), along i across the four waves
-//           through LDS; each wave then owns one tile row = 32 output pixels x 32 couts as a patch and runs the
-//           common fused epilogue (patch_tail) with a row -> pixel table.
-// Two workgroups per CU (78 KB LDS each): one transforms while the other multiplies.
+//           through LDS (32 KB exchange buffer over the raw ring); each wave then owns one tile row = 32 output pixels x
+//           32 couts as a patch and runs the common fused epilogue (patch_tail) with a row -> pixel table.
+// 118 VGPRs and 32.5 KB of LDS: four workgroups per CU.  History and measurements: DESIGN.md section 3.
 // ---------------------------------------------------------------------------------------------------------
 // tiles per region: 4 x 8 (8 x 16 output pixels, "wide") or 8 x 4 (16 x 8, "tall"), whichever wastes fewer pixels on the
 // image's ragged edge (90 x 120: 96 x 128 = +13.8 % wide, 96 x 120 = +6.7 % tall); the patch is 10 x 18 or 18 x 10 pixels
@@ -1445,7 +1447,7 @@ __host__ __device__ inline int wino_tall(int Ho, int Wo) {
 static constexpr int WG_KC = 8;                             // channels per chunk
 static constexpr int WG_PLANE = 192;                        // cells per channel-quad plane of a raw buffer (180 live)
 static constexpr int WG_RAW = 512 * 4;                      // floats per raw buffer: two planes of 16-byte slots, padded to 2 x 256 slots
-static constexpr int WG_UV = 16 * 32 * WG_KC;               // floats per U / V buffer (4096)
+static constexpr int WG_UV = 16 * 32 * WG_KC;               // floats of a chunk's U block (4096)
 
 #ifndef WG_ABL
 #define WG_ABL 0
