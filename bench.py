@@ -346,7 +346,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el2 = float(t.item())
         # agreement of the two arithmetic modes on the last frame (both ran the same sequence length)
-        alt = {"precision": "f16x3 (operands split hi+lo into f16, 3 x v_mfma_f32_32x32x16_f16, fp32 accumulate)",
+        alt = {"precision": "f16x3 (operands split hi+lo into f16, 3 x v_mfma_f32_32x32x16_f16, fp32 accumulate; 3x3 layers on the exact-fp32 Winograd kernel)",
                "value": round(world * B * a.steps / el2, 2), "unit": "frames/s", "ms_per_step": round(el2 / a.steps * 1e3, 3),
                "opt_in": "module.precision = 'f16x3' or CF_PRECISION=f16x3"}
         del m2

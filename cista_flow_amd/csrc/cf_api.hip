@@ -40,7 +40,7 @@ struct RawWeight {
 
 struct PackedConv {
     float* w = nullptr;
-    float* wino = nullptr;   // Winograd F(2x2,3x3) transform of w (3x3 convs, fp32 mode; conv_wino_kernel)
+    float* wino = nullptr;   // Winograd F(2x2,3x3) transform of w (3x3 convs, fp32 and f16x3 modes; conv_wino_kernel)
     void* w16 = nullptr;     // f16 hi/lo split copy (precision != 0)
     float* bias = nullptr;
     int cout = 0, cin = 0, cin_pad = 0, KH = 0, KW = 0, Ktot = 0, rows = 0;
@@ -766,8 +766,9 @@ extern "C" int cf_finalize_weights(cf_handle* h, void* stream) {
             h->has_flow = true;
         }
     }
-    if (h->cfg.precision == 0) {
-        // fp32: every plain 3x3 matrix also gets its Winograd transform U = G g G^T (16/9 of its size), made from the
+    if (h->cfg.precision == 0 || h->cfg.precision == 3) {
+        // fp32 (and f16x3, whose 3x3 layers run on the exact-fp32 Winograd kernel: it is faster than three f16 MFMAs per product
+        // on the direct kernel): every plain 3x3 matrix also gets its Winograd transform U = G g G^T (16/9 of its size), made from the
         // PACKED matrix so that BatchNorm folds, row stacking / interleaving and channel slices carry over
         for (auto& kv : h->conv) {
             PackedConv& pc = kv.second;

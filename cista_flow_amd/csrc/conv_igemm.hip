@@ -1962,7 +1962,7 @@ int conv_stats_chunks(const ConvParams& p, int tile) {
 }
 
 static bool wino_ok(const ConvParams& p) {
-    if (p.a_mode != A_NHWC || p.prec != 0 || !p.w_wino || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.padT != 1 || p.padL != 1) return false;
+    if (p.a_mode != A_NHWC || (p.prec != 0 && p.prec != 3) || !p.w_wino || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.padT != 1 || p.padL != 1) return false;
     if (p.Ho != p.Hin || p.Wo != p.Win || p.Hin < 12 || p.Win < 12) return false;
     if (p.w_bs != 0 && p.w_div <= 1) return false;          // per-image matrices (correlation GEMM); weight groups are fine
     for (int i = 0; i < p.nseg; ++i)
