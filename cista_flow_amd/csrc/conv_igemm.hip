@@ -2332,7 +2332,8 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
     if (tile == 0 && wino_ok(p)) {
         const long tb = p.tile_batch > 0 ? p.tile_batch : batch;
         const long wg = (long)wino_regions(p.Ho, p.Wo) * ((p.cout + 31) / 32) * tb;
-        if (wg >= 128) tile = 40;      // (the eight-wave tile 41 measured -3..+6 % per layer, -1.4 % on the whole step: explicit only)
+        static const long wmin = getenv("CF_WINO_MIN") ? atol(getenv("CF_WINO_MIN")) : 128;
+        if (wg >= wmin) tile = 40;      // (the eight-wave tile 41 measured -3..+6 % per layer, -1.4 % on the whole step: explicit only)
     }
     if (tile == 0) {
         // Pick the largest tile that still yields >= ~2 workgroups per CU (measured with tools/conv_bench.py on

@@ -1,4 +1,6 @@
-# tuning: whole-step throughput under library knobs (GPU box)
-for kv in "X=0" "CF_CISTA_CHAINS=1" "CF_CISTA_CHAINS=2" "CF_CISTA_CHAINS=4" "CF_ENC_PAIR=1" "CF_PHASES=1"; do
-  echo "== $kv"; env $kv python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-alt --no-roofline 2>&1 | grep -o '"value": [0-9.]*\|phases[^}]*}' | head -3
+# tuning: whole-step throughput under library knobs (GPU box).  usage: tools/knobs.sh "A=1" "B=2 C=3" ...
+for kv in "$@"; do
+  for rep in 1 2; do
+    echo "== $kv: $(env $kv python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-alt --no-roofline ${BENCH_ARGS} 2>&1 | grep -o '"value": [0-9.]*' | head -1)"
+  done
 done
