@@ -2,6 +2,8 @@
 """bench.py -- reconstructed frames/s of the cista-eiflow hot path on MI355X (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 20 --warmup 4
+    python bench.py --gpus N ...            (no torchrun environment: starts the N-rank job itself as a child process)
+    python bench.py --gpus 8 --strong 32 --height 480 --width 640      (configs[3]: 32 sequences split over the ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -52,7 +54,34 @@ def parse():
     ap.add_argument("--no-alt", action="store_true", help="skip the extra f16x3-precision timing leg")
     ap.add_argument("--model", default="eiflow", choices=["eiflow", "eraft", "idnet"],
                     help="flow network (the BASELINE metric is eiflow; the others are extra workloads)")
+    ap.add_argument("--strong", type=int, default=0, metavar="SEQUENCES",
+                    help="strong scaling: a FIXED total of SEQUENCES (configs[3]: 32) split over the N ranks "
+                         "(contiguous shards, parallel.shard_range) instead of --batch sequences per GPU")
     return ap.parse_args()
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the one-process-per-GPU job ourselves as a
+    CHILD process (torch.distributed.run), before this process has made any HIP call -- a process that has touched the GPU
+    must never be replaced or fork GPU work -- relay rank 0's JSON line and exit with the child's return code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", CF_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True)
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{"):
+            print(ln, flush=True)
+        elif ln.strip():
+            print(ln, file=sys.stderr, flush=True)
+    raise SystemExit(r.returncode)
 
 
 def model_args(H, W):
@@ -205,9 +234,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        self_launch(a)                      # never returns
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (a.gpus, a.gpus))
+        raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d" % (a.gpus, world, a.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     # CF_BENCH_REHEARSE=1: control-flow rehearsal of the N > 1 path on a box with ONE GPU (all ranks share cuda:0,
@@ -241,8 +271,14 @@ def main():
 
     import weights_util as wu
     from cista_flow_amd.e2v.e2v_model import DCEIFlowCistaNet, ERAFTCistaNet, IDCistaNet
-    from cista_flow_amd.parallel import collate_frames
+    from cista_flow_amd.parallel import collate_frames, shard_range
     B, H, W = a.batch, a.height, a.width
+    if a.strong:
+        s0, s1 = shard_range(a.strong, rank, world)
+        B = s1 - s0
+        if B < 1:
+            raise SystemExit("--strong %d leaves rank %d of %d without a sequence" % (a.strong, rank, world))
+    total_seq = a.strong if a.strong else world * B
     cls = {"eiflow": DCEIFlowCistaNet, "eraft": ERAFTCistaNet, "idnet": IDCistaNet}[a.model]
     model = cls(model_args(H, W)).eval()
     wu.fill_module(model, 1234)
@@ -276,7 +312,7 @@ def main():
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 I.record_stream(side)          # I was allocated on the main stream; keep it alive for the gather
-                state["gathered"] = collate_frames(I.cpu() if rehearse else I, force=force_dist)
+                state["gathered"] = collate_frames(I.cpu() if rehearse else I, n_sequences=a.strong or None, force=force_dist)
         return I
 
     with torch.no_grad():
@@ -301,10 +337,6 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     assert torch.isfinite(state["prev"]).all(), "non-finite reconstruction"
-
-    roofline = None
-    if not a.no_roofline and rank == 0:
-        roofline = roofline_pass(model, step, B, dev, min(a.steps, 10))
 
     alt = None
     if not a.no_alt and os.environ.get("CF_PRECISION") is None:
@@ -347,27 +379,40 @@ def main():
             el2 = float(t.item())
         # agreement of the two arithmetic modes on the last frame (both ran the same sequence length)
         alt = {"precision": "f16x3 (operands split hi+lo into f16, 3 x v_mfma_f32_32x32x16_f16, fp32 accumulate; 3x3 layers on the exact-fp32 Winograd kernel)",
-               "value": round(world * B * a.steps / el2, 2), "unit": "frames/s", "ms_per_step": round(el2 / a.steps * 1e3, 3),
+               "value": round(total_seq * a.steps / el2, 2), "unit": "frames/s", "ms_per_step": round(el2 / a.steps * 1e3, 3),
                "opt_in": "module.precision = 'f16x3' or CF_PRECISION=f16x3"}
         del m2
+
+    # rank 0's roofline pass (no collectives inside) comes AFTER every timed leg and its barriers, so the other ranks only
+    # wait for it at the final barrier before tearing the process group down
+    roofline = None
+    if not a.no_roofline and rank == 0:
+        roofline = roofline_pass(model, step, B, dev, min(a.steps, 10))
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.model == "eiflow":
         cpu = cpu_baseline(B, H, W, a.cpu_frames)
 
     if rank == 0:
-        value = world * B * a.steps / el
+        value = total_seq * a.steps / el
+        rccl = None
+        if dist_on and not rehearse:
+            try:
+                rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                rccl = None
         out = {
             "metric": "reconstructed frames/sec at %dx%d, cista-%s" % (H, W, a.model), "value": round(value, 2), "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if a.strong else "weak", "vs_baseline": None,
+            "n_ranks_seen": dist.get_world_size() if dist_on else 1, "collective_backend": (("gloo (rehearsal)" if rehearse else "rccl " + str(rccl)) if dist_on else None),
             "dtype": {"f32": "f32", "f16x3": "f16x3->f32acc", "f16": "f16->f32acc"}[os.environ.get("CF_PRECISION", "f32")],
             "data": "synthetic",
             "config": {"workload": "cista-%s %dx%d batch=%d sequences per GPU (BASELINE configs[%d]), flow iters %d, "
                                    "CISTA depth 5, seeded random weights" % (a.model, H, W, B,
                                                                             {"eiflow": 3 if (H, W) == (480, 640) else 1, "eraft": 2, "idnet": 4}[a.model],
                                                                             model.flow_iters),
-                       "sequences_per_gpu": B, "height": H, "width": W, "parallelism": "dp%d (independent sequences)" % world},
+                       "sequences_per_gpu": B, "total_sequences": total_seq, "height": H, "width": W, "parallelism": "dp%d (independent sequences)" % world},
             "roofline": roofline, "cpu_baseline": cpu, "alt_precision": alt,
         }
         print(json.dumps(out), flush=True)

@@ -41,3 +41,21 @@ def test_bench_single_rank_rccl_path(gpu):
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["value"] > 0
+
+
+def test_bench_self_launch_two_ranks(gpu):
+    """`python bench.py --gpus 2` without a torchrun environment starts the two-rank job itself (child process, before any HIP
+    call) and relays rank 0's single JSON line; here the ranks share the one GPU over gloo (CF_BENCH_REHEARSE=1).  Also the
+    strong-scaling split: 3 sequences over 2 ranks (ragged shards 2 + 1, padded all-gather)."""
+    env = dict(os.environ, CF_BENCH_REHEARSE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--strong", "3",
+           "--height", "128", "--width", "128", "--no-alt"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["scaling"] == "strong"
+    assert out["config"]["total_sequences"] == 3 and out["value"] > 0

@@ -94,3 +94,22 @@ def test_traffic_table_uses_the_library_kernel_names():
     assert conv, "no conv kernels in profiles/hbm_traffic.json"
     for k in conv:
         assert k in names, k
+
+
+def test_bench_self_launch_relays_child_exit_code():
+    """`python bench.py --gpus 2` with no torchrun environment must start the two-rank job itself instead
+    of raising.  Without a GPU every rank stops at "needs an MI355X": the launcher has to relay that failure as its own
+    non-zero exit code and must not print a JSON line."""
+    import subprocess
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("GPU present: covered by tests/test_bench_gpu.py")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "needs an MI355X" in r.stderr, r.stderr[-1500:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
