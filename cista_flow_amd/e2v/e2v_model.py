@@ -86,7 +86,10 @@ class CistaLSTCNet(nn.Module):
         hh, cc = empty_nhwc(*s1, dev), empty_nhwc(*s1, dev)
         h = self._be().get(B, dev)
         p = _lib.ptr
-        h.check(h.lib.cf_cista_forward(h.h, p(events.contiguous()), p(prev_image.contiguous()), p(c_prev), p(z_prev),
+        # contiguous copies stay bound until the call returns: ptr() keeps only the address, and a freed temporary's block
+        # would be handed to the next .contiguous() (two arguments aliasing one buffer)
+        ev_c, img_c = events.contiguous(), prev_image.contiguous()
+        h.check(h.lib.cf_cista_forward(h.h, p(ev_c), p(img_c), p(c_prev), p(z_prev),
                                        p(h_prev), p(cc_prev), p(I), p(c), p(z), p(hh), p(cc),
                                        _lib.current_stream_ptr(dev)), "cf_cista_forward")
         return I, [c, z, (hh, cc)]
@@ -146,7 +149,8 @@ class _HipFlowRec(BaseFlowRec):
         hh, cc = empty_nhwc(*s1, dev), empty_nhwc(*s1, dev)
         h = self._be().get(B, dev)
         p = _lib.ptr
-        h.check(h.lib.cf_step(h.h, p(in0.contiguous()), p(in1.contiguous()), p(rec0.contiguous()), p(flow_init),
+        in0_c, in1_c, rec0_c = in0.contiguous(), in1.contiguous(), rec0.contiguous()   # bound until the call returns
+        h.check(h.lib.cf_step(h.h, p(in0_c), p(in1_c), p(rec0_c), p(flow_init),
                               p(gt_flow), p(c_prev), p(z_prev), p(h_prev), p(cc_prev), p(I), p(flow_final), p(flow_low),
                               p(preds), p(z_warp), p(c), p(z), p(hh), p(cc), _lib.current_stream_ptr(dev)), "cf_step")
         if z_warp is not None:
@@ -267,8 +271,8 @@ class IDCistaNet(_HipFlowRec):
         hh, cc = empty_nhwc(*s1, dev), empty_nhwc(*s1, dev)
         h = self._be().get(B, dev)
         p = _lib.ptr
-        evc = ev.contiguous()
-        h.check(h.lib.cf_step(h.h, p(evc), p(evc), p(rec0.contiguous()), p(flow_init), p(gt_flow), p(c_prev), p(z_prev),
+        evc, rec0_c = ev.contiguous(), rec0.contiguous()                                # bound until the call returns
+        h.check(h.lib.cf_step(h.h, p(evc), p(evc), p(rec0_c), p(flow_init), p(gt_flow), p(c_prev), p(z_prev),
                               p(h_prev), p(cc_prev), p(I), p(flow_final), p(next_flow), p(hist), p(z_warp), p(c), p(z),
                               p(hh), p(cc), _lib.current_stream_ptr(dev)), "cf_step")
         if z_warp is not None:

@@ -60,7 +60,8 @@ class IDEDEQIDO(nn.Module):
         flow_final = torch.empty((B, 2, H, W), dtype=torch.float32, device=dev)
         next_flow = torch.empty((B, 2, Hp, Wp), dtype=torch.float32, device=dev)
         hist = torch.empty((2, B, 2, Hp, Wp), dtype=torch.float32, device=dev)
-        h.check(h.lib.cf_flow_forward(h.h, _lib.ptr(event_bins.contiguous()), None, _lib.ptr(flow_init), _lib.ptr(flow_final),
+        bins_c = event_bins.contiguous()                   # bound until the call returns (ptr() keeps only the address)
+        h.check(h.lib.cf_flow_forward(h.h, _lib.ptr(bins_c), None, _lib.ptr(flow_init), _lib.ptr(flow_final),
                                       _lib.ptr(next_flow), _lib.ptr(hist), _lib.current_stream_ptr(dev)), "cf_flow_forward")
         d0 = flow_init if flow_init is not None else torch.zeros_like(hist[1])
         return {'flow_final': flow_final, 'next_flow': next_flow, 'delta_flow': torch.stack([d0, hist[1]], 1),

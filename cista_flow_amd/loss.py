@@ -32,8 +32,9 @@ def recon_metrics(rec_img, target_img):
     dev = a.device
     out = torch.empty(2, dtype=torch.float64, device=dev)
     L = _lib.load()
+    scratch = _scratch(dev)
     with torch.cuda.device(dev):
-        _check(L.cf_metrics_recon(_lib.ptr(a), _lib.ptr(b), a.numel(), _lib.ptr(out), _lib.ptr(_scratch(dev)),
+        _check(L.cf_metrics_recon(_lib.ptr(a), _lib.ptr(b), a.numel(), _lib.ptr(out), _lib.ptr(scratch),
                                   _lib.current_stream_ptr(dev)), "cf_metrics_recon")
     return out
 
@@ -82,11 +83,13 @@ def flow_metrics(flow_final, gt_flow, gt_img0, gt_img1, flow_valid=None, warp_mo
     dev = flow_final.device
     out = torch.empty(6, dtype=torch.float64, device=dev)
     L = _lib.load()
+    # every contiguous copy and the scratch buffer stay bound to a local until the call has returned: ptr() keeps only the
+    # address, and a temporary freed between two arguments would hand its block to the next one (aliased inputs, epe = 0)
+    ff, gf, g0, g1, scratch = flow_final.contiguous(), gt_flow.contiguous(), gt_img0.contiguous(), gt_img1.contiguous(), _scratch(dev)
     with torch.cuda.device(dev):
-        _check(L.cf_metrics_flow(_lib.ptr(flow_final.contiguous()), _lib.ptr(gt_flow.contiguous()), _lib.ptr(gt_img0.contiguous()),
-                                 _lib.ptr(gt_img1.contiguous()), _lib.ptr(flow_valid), B, H, W,
+        _check(L.cf_metrics_flow(_lib.ptr(ff), _lib.ptr(gf), _lib.ptr(g0), _lib.ptr(g1), _lib.ptr(flow_valid), B, H, W,
                                  _lib.CF_WARP_FORWARD if warp_mode == 'forward' else _lib.CF_WARP_BACKWARD, float(max_flow),
-                                 _lib.ptr(out), _lib.ptr(_scratch(dev)), _lib.current_stream_ptr(dev)), "cf_metrics_flow")
+                                 _lib.ptr(out), _lib.ptr(scratch), _lib.current_stream_ptr(dev)), "cf_metrics_flow")
     return out
 
 
@@ -119,9 +122,10 @@ def fwl_metrics(voxel, flow):
     dev = voxel.device
     out = torch.empty(3, dtype=torch.float64, device=dev)
     L = _lib.load()
+    vx, fl, scratch = voxel.contiguous(), flow.contiguous(), _scratch(dev)      # bound until the call returns
     with torch.cuda.device(dev):
-        _check(L.cf_metrics_fwl(_lib.ptr(voxel.contiguous()), _lib.ptr(flow.contiguous()), B, C, H, W, _lib.ptr(out),
-                                _lib.ptr(_scratch(dev)), _lib.current_stream_ptr(dev)), "cf_metrics_fwl")
+        _check(L.cf_metrics_fwl(_lib.ptr(vx), _lib.ptr(fl), B, C, H, W, _lib.ptr(out),
+                                _lib.ptr(scratch), _lib.current_stream_ptr(dev)), "cf_metrics_fwl")
     return out
 
 

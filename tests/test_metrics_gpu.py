@@ -81,3 +81,28 @@ def test_metrics_vs_oracle_batched(gpu):
     r = recon_metrics(i0.to(gpu), i1.to(gpu)).cpu()
     mse, psnr = orc.recon_metrics(i0, i1)
     assert close(r[0], mse, 1e-9) and abs(float(r[1]) - psnr) < 1e-9
+
+
+def test_metrics_noncontiguous_inputs(gpu):
+    """Sliced / permuted inputs: every `.contiguous()` copy must outlive the launch -- with both flow and gt
+    non-contiguous a freed first copy used to hand its block to the second one (aliased arguments, epe = 0)."""
+    from cista_flow_amd.loss import flow_metrics, fwl_metrics, recon_metrics
+    gen = torch.Generator().manual_seed(11)
+    B, H, W = 2, 48, 80
+    flow_w = (3.0 * torch.randn(B, 2, H, 2 * W, generator=gen)).to(gpu)
+    gt_w = (flow_w.cpu() + torch.randn(B, 2, H, 2 * W, generator=gen)).to(gpu)
+    i0_w = torch.rand(B, 1, H, 2 * W, generator=gen).to(gpu)
+    i1_w = torch.rand(B, 1, H, 2 * W, generator=gen).to(gpu)
+    flow, gt, i0, i1 = flow_w[..., ::2], gt_w[..., ::2], i0_w[..., ::2], i1_w[..., ::2]
+    assert not flow.is_contiguous() and not gt.is_contiguous()
+    for mode in ("forward", "backward"):
+        got = flow_metrics(flow, gt, i0, i1, None, mode)
+        ref = flow_metrics(flow.clone(memory_format=torch.contiguous_format), gt.clone(memory_format=torch.contiguous_format),
+                           i0.clone(memory_format=torch.contiguous_format), i1.clone(memory_format=torch.contiguous_format), None, mode)
+        assert torch.equal(got, ref) and float(got[1]) > 0.5, (mode, got, ref)
+    evs_w = wu.synth_events(B, 5, H, 2 * W, 3).to(gpu)
+    evs = evs_w[..., ::2]
+    assert torch.equal(fwl_metrics(evs, flow), fwl_metrics(evs.clone(memory_format=torch.contiguous_format),
+                                                           flow.clone(memory_format=torch.contiguous_format)))
+    assert torch.equal(recon_metrics(i0, i1), recon_metrics(i0.clone(memory_format=torch.contiguous_format),
+                                                            i1.clone(memory_format=torch.contiguous_format)))
