@@ -2053,6 +2053,13 @@ extern "C" int cf_events_to_voxel_ex(const double* events, const int64_t* offset
                                   static_cast<hipStream_t>(stream), hot_pixel_threshold) == hipSuccess ? CF_OK : CF_ERR_HIP;
 }
 
+// event_preprocess(mode='std') of voxel grids that are already on the device (event_process.py:193-216), in place
+extern "C" int cf_voxel_preprocess(float* voxel, int B, long long voxels_per_grid, double* stats_scratch, int normalize,
+                                   float hot_pixel_threshold, void* stream) {
+    return launch_voxel_preprocess(voxel, B, (long)voxels_per_grid, stats_scratch, normalize, hot_pixel_threshold,
+                                   static_cast<hipStream_t>(stream)) == hipSuccess ? CF_OK : CF_ERR_HIP;
+}
+
 extern "C" int cf_op_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, void* stream) {
     return launch_nchw_to_nhwc(src, dst, C, B, C, H * W, static_cast<hipStream_t>(stream)) == hipSuccess ? CF_OK : CF_ERR_HIP;
 }

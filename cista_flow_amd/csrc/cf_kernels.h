@@ -219,6 +219,9 @@ hipError_t launch_idn_deblur(const float* bins, const float* flow, float* out, i
 hipError_t launch_events_to_voxel(const double* events, const long* offsets, int B, int bins, int H, int W,
                                   float* voxel, double* stats, int normalize, hipStream_t s, float hot = 0.f);
 
+// event_preprocess('std', filter_hot_pixel) of B device-resident grids of per_seq voxels each, in place
+hipError_t launch_voxel_preprocess(float* voxel, int B, long per_seq, double* stats, int normalize, float hot, hipStream_t s);
+
 // layout helpers for the Python boundary / tests
 hipError_t launch_nchw_to_nhwc(const float* src, float* dst, int dst_ld, int B, int C, int HW, hipStream_t s);
 hipError_t launch_nhwc_to_nchw(const float* src, int src_ld, float* dst, int B, int C, int HW, hipStream_t s);

@@ -839,7 +839,7 @@ __global__ void voxel_stats_kernel(const float* __restrict__ voxel, long per_seq
 
 __global__ void voxel_normalize_kernel(float* __restrict__ voxel, long per_seq, const double* __restrict__ stats, float hot) {
     const int b = blockIdx.y;
-    const double cnt = stats[b * 3 + 0];
+    const double cnt = stats ? stats[b * 3 + 0] : 0.0;      // stats == nullptr: the hot-pixel filter alone
     if (cnt <= 0 && !(hot > 0.f)) return;
     const double mean = cnt > 0 ? stats[b * 3 + 1] / cnt : 0.0;
     const double sd = cnt > 0 ? sqrt(stats[b * 3 + 2] / cnt - mean * mean) : 1.0;
@@ -867,6 +867,28 @@ hipError_t launch_events_to_voxel(const double* events, const long* offsets, int
         hipLaunchKernelGGL(voxel_stats_kernel, dim3(64, B), dim3(256), 0, s, voxel, per_seq, stats, hot);
         note_launch("voxel_normalize_kernel", dim3(64, B), dim3(256));
         hipLaunchKernelGGL(voxel_normalize_kernel, dim3(64, B), dim3(256), 0, s, voxel, per_seq, stats, hot);
+    } else if (hot > 0.f) {
+        // event_preprocess applies the hot-pixel filter whatever the normalisation mode (event_process.py:196-198)
+        note_launch("voxel_normalize_kernel", dim3(64, B), dim3(256));
+        hipLaunchKernelGGL(voxel_normalize_kernel, dim3(64, B), dim3(256), 0, s, voxel, per_seq, (const double*)nullptr, hot);
+    }
+    return hipGetLastError();
+}
+
+// event_preprocess(mode='std') of grids that already sit on the device (event_process.py:193-216), in place: optional
+// hot-pixel filter, then mean 0 / std 1 over the non-zero voxels of each of the B grids
+hipError_t launch_voxel_preprocess(float* voxel, int B, long per_seq, double* stats, int normalize, float hot, hipStream_t s) {
+    if (!voxel || B <= 0 || per_seq <= 0 || (normalize && !stats)) return hipErrorInvalidValue;
+    if (normalize) {
+        hipError_t e = hipMemsetAsync(stats, 0, sizeof(double) * 3 * B, s);
+        if (e != hipSuccess) return e;
+        note_launch("voxel_stats_kernel", dim3(64, B), dim3(256));
+        hipLaunchKernelGGL(voxel_stats_kernel, dim3(64, B), dim3(256), 0, s, voxel, per_seq, stats, hot);
+        note_launch("voxel_normalize_kernel", dim3(64, B), dim3(256));
+        hipLaunchKernelGGL(voxel_normalize_kernel, dim3(64, B), dim3(256), 0, s, voxel, per_seq, stats, hot);
+    } else if (hot > 0.f) {
+        note_launch("voxel_normalize_kernel", dim3(64, B), dim3(256));
+        hipLaunchKernelGGL(voxel_normalize_kernel, dim3(64, B), dim3(256), 0, s, voxel, per_seq, (const double*)nullptr, hot);
     }
     return hipGetLastError();
 }

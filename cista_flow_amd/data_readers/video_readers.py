@@ -1,10 +1,10 @@
-"""Frame / event packaging for one reconstruction (reference: data_readers/video_readers.py:10-234, class VR).
+"""Frame / event packaging for one reconstruction (reference: data_readers/video_readers.py:10-282, class VR).
 
 `VR` keeps the reference's attributes and method names; a dataset-specific reader overrides `update_frame`,
 `update_events` (and `update_flow`) exactly as the reference's ImageReader / VideoReader subclasses do -- those
 subclasses themselves (cv2.imread / cv2.VideoCapture / h5py loaders) are file-format plumbing that needs packages
 absent here and are not restated.  What IS on the way to the hot path is the event side of `update_event_frame_pack` /
-`update_event_frame_pack_fix`: accumulate windows up to an event budget, crop to the sensor, split by the budget and
+`update_event_frame_pack_fix` / `update_event_frame_flow_pack` (the one test_with_flow.py:121 calls): accumulate windows up to an event budget, crop to the sensor, split by the budget and
 build the normalised voxel grids -- the last step runs on the GPU here (one cf_events_to_voxel call for all windows of
 a pack: float atomics, so sums may differ from np.add.at in the last bit) and the grids are returned as CUDA tensors.
 """
@@ -122,6 +122,26 @@ class VR:
         if limit_num_events <= 0 or mode == 'upsampled':
             return self._voxels([window], False), frame_pack, gt_frame
         return self._voxels(self._split(window, limit_num_events), True), frame_pack, gt_frame
+
+    def update_event_frame_flow_pack(self, mode='upsampled'):
+        """video_readers.py:237-282 -- what test_with_flow.py:121 calls: one ground-truth frame, the flow from the previous
+        frame to it (`update_flow(prev, gt)` of the dataset-specific reader) and ALL events in between as one normalised
+        voxel grid (no hot-pixel filter).  Returns (event_windows, frame_pack, gt_frame, flow_list)."""
+        assert mode == 'upsampled', "Data mode can not be 'real'!"
+        frame_pack = []
+        if self.frame_id == 0:
+            self.prev_frame, _ = self.update_frame()
+        frame_pack.append(self.prev_frame)
+        gt_frame, _ = self.update_frame()
+        flow = self.update_flow(self.prev_frame, gt_frame)
+        self.prev_frame = gt_frame
+        window = self.update_events()
+        if window is None:
+            window = np.zeros((0, 4))
+        if self.frame_id >= self.num_frames:
+            self.ending = True
+        self.num_events = len(window)
+        return self._voxels([window], False), frame_pack, gt_frame, [flow]
 
     @staticmethod
     def _split(window, limit_num_events):

@@ -21,7 +21,7 @@ SYMBOLS = [
     "cf_op_conv2d", "cf_op_instance_norm_relu", "cf_op_corr_lookup", "cf_op_nchw_to_nhwc",
     "cf_op_nhwc_to_nchw", "cf_profile_enable", "cf_profile_read", "cf_conv_tile_name", "cf_profile_report", "cf_op_conv2d_bench", "cf_events_to_voxel", "cf_op_conv2d_inorm_stats", "cf_quantize_u8", "cf_hint_prev_grid",
     "cf_profile_report_json", "cf_metrics_scratch_doubles", "cf_metrics_recon", "cf_metrics_flow", "cf_metrics_fwl",
-    "cf_graph_enable", "cf_graph_stats", "cf_events_to_voxel_ex",
+    "cf_graph_enable", "cf_graph_stats", "cf_events_to_voxel_ex", "cf_voxel_preprocess",
 ]
 
 
@@ -89,6 +89,8 @@ def load():
     lib.cf_events_to_voxel.restype = i
     lib.cf_events_to_voxel_ex.argtypes = [fp, fp, i, i, i, i, fp, fp, i, C.c_float, vp]
     lib.cf_events_to_voxel_ex.restype = i
+    lib.cf_voxel_preprocess.argtypes = [fp, i, C.c_longlong, fp, i, C.c_float, vp]
+    lib.cf_voxel_preprocess.restype = i
     lib.cf_quantize_u8.argtypes = [fp, fp, C.c_longlong, vp]
     lib.cf_quantize_u8.restype = i
     lib.cf_metrics_scratch_doubles.argtypes = []

@@ -35,3 +35,26 @@ def events_to_voxel_grid_batch(event_list, num_bins, width, height, normalize=Tr
     if rc != 0:
         raise RuntimeError("cf_events_to_voxel failed (%d)" % rc)
     return voxel
+
+
+def event_preprocess(event_voxel_grid, mode='std', filter_hot_pixel=False):
+    """event_preprocess of the reference (utils/event_process.py:193-216) for grids that already sit on the GPU:
+    [bins, H, W] or [B, bins, H, W] float32 CUDA tensor -> new tensor of the same shape; each grid is filtered
+    (|v| > 25 / bins -> 0) and normalised to mean 0 / std 1 over its non-zero voxels on its own."""
+    if mode != 'std':
+        raise NotImplementedError("event_preprocess: only mode='std' is used by CISTA-Flow")
+    _lib.check_f32_cuda(event_voxel_grid, "event_voxel_grid")
+    if event_voxel_grid.dim() not in (3, 4):
+        raise ValueError("event_voxel_grid must be [bins,H,W] or [B,bins,H,W]")
+    g = event_voxel_grid.contiguous().clone()
+    B = 1 if g.dim() == 3 else g.shape[0]
+    bins = g.shape[-3]
+    dev = g.device
+    stats = torch.empty((B, 3), dtype=torch.float64, device=dev)
+    L = _lib.load()
+    with torch.cuda.device(dev):
+        rc = L.cf_voxel_preprocess(_lib.ptr(g), B, g.numel() // B, _lib.ptr(stats), 1, (25.0 / bins) if filter_hot_pixel else 0.0,
+                                   _lib.current_stream_ptr(dev))
+    if rc != 0:
+        raise RuntimeError("cf_voxel_preprocess failed (%d)" % rc)
+    return g

@@ -133,6 +133,13 @@ int cf_events_to_voxel(const double* events, const int64_t* offsets, int B, int 
 int cf_events_to_voxel_ex(const double* events, const int64_t* offsets, int B, int bins, int H, int W, float* voxel,
                           double* stats_scratch, int normalize, float hot_pixel_threshold, void* stream);
 
+/* event_preprocess(grid, mode='std', filter_hot_pixel) (utils/event_process.py:193-216) of B grids that already sit on the
+ * device ([B][voxels_per_grid] fp32, in place): zero |v| > hot_pixel_threshold (<= 0: off), then -- normalize != 0 -- mean 0 /
+ * std 1 over each grid's non-zero voxels.  Used where the reference crops a grid before normalising it
+ * (data_readers/MVSEC.py:389-403).  stats_scratch: 3*B doubles (may be NULL when normalize == 0). */
+int cf_voxel_preprocess(float* voxel, int B, long long voxels_per_grid, double* stats_scratch, int normalize,
+                        float hot_pixel_threshold, void* stream);
+
 /* f-2  output stage, `np.uint8(pred_image * 255.)` (test_with_flow.py:174): fp32 product, truncation toward zero,
  * on the device (img: n floats in [0,1], out: n bytes).  Stateless, asynchronous on `stream`.  The PNG encoder and the
  * flow -> HSV colour coding (utils/data_io.py:9-29, defined by cv2.cartToPolar / cvtColor) stay on the host. */

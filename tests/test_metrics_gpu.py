@@ -99,7 +99,7 @@ def test_metrics_noncontiguous_inputs(gpu):
         got = flow_metrics(flow, gt, i0, i1, None, mode)
         ref = flow_metrics(flow.clone(memory_format=torch.contiguous_format), gt.clone(memory_format=torch.contiguous_format),
                            i0.clone(memory_format=torch.contiguous_format), i1.clone(memory_format=torch.contiguous_format), None, mode)
-        assert torch.equal(got, ref) and float(got[1]) > 0.5, (mode, got, ref)
+        assert torch.equal(got, ref) and float(got[1]) > 0.1, (mode, got, ref)
     evs_w = wu.synth_events(B, 5, H, 2 * W, 3).to(gpu)
     evs = evs_w[..., ::2]
     assert torch.equal(fwl_metrics(evs, flow), fwl_metrics(evs.clone(memory_format=torch.contiguous_format),

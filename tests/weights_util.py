@@ -103,3 +103,90 @@ def synth_event_file(path, seed=5, n=6000, width=36, height=28, duration=0.5, ov
         for i in range(n):
             f.write("%.9f %d %d %d\n" % (t[i], x[i], y[i], p[i]))
     return np.stack([t, x, y, p], 1).astype(np.float64)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# A synthetic stand-in for one MVSEC sequence (data_readers/MVSEC.py reads `<split>_data.hdf5` / `<split>_gt.hdf5`):
+# mappings with .get('davis/left/...') whose values index like h5py datasets (slices come back as COPIES).
+# Frames and flow maps are generated on access from (seed, index), so nothing large is ever held.
+# ---------------------------------------------------------------------------------------------------------
+class _LazyDataset(object):
+    def __init__(self, n, make, dtype):
+        self.n, self.make, self.dtype = n, make, dtype
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            idx = range(*i.indices(self.n))
+            return np.stack([self.make(j) for j in idx]) if len(idx) else np.zeros((0,), self.dtype)
+        return self.make(int(i))
+
+
+class _ArrayDataset(object):
+    def __init__(self, a):
+        self.a = a
+
+    def __len__(self):
+        return len(self.a)
+
+    def __getitem__(self, i):
+        return np.array(self.a[i])            # h5py hands out copies
+
+    def __array__(self, dtype=None, copy=None):
+        return np.array(self.a, dtype=dtype)
+
+
+class _Mapping(object):
+    def __init__(self, d):
+        self.d = d
+
+    def get(self, k):
+        return self.d[k]
+
+
+MVSEC_SPLIT, MVSEC_FIRST = 'indoor_flying4', 196      # Valid_Time_Index['indoor_flying4'] = [196, 570]: the shortest sequence
+
+
+def synth_mvsec_source(seed=3, n_items=10, width=346, height=260):
+    """-> (data, gt): `n_items` image intervals of ~4-7 k events each after image MVSEC_FIRST.  Image period 20 ms, flow maps
+    every 50 ms; some image intervals lie inside one flow interval (single-interval ground truth), others straddle two."""
+    rng = np.random.default_rng([int(seed), 5151])
+    n_img = 572
+    img_ts = 10.0 + 0.02 * np.arange(n_img, dtype=np.float64)
+    counts = rng.integers(4000, 7000, n_items)
+    rows = []
+    for k in range(n_items):
+        t0, t1 = img_ts[MVSEC_FIRST + k], img_ts[MVSEC_FIRST + k + 1]
+        n = int(counts[k])
+        t = np.sort(rng.uniform(t0, t1, n))
+        x, y = rng.integers(0, width, n), rng.integers(0, height, n)
+        p = rng.integers(0, 2, n) * 2 - 1
+        hot = np.arange(0, n, 11)
+        x[hot], y[hot], p[hot] = 123, 77, 1           # one hot pixel: |voxel| > 25 / bins
+        rows.append(np.stack([x, y, t, p], 1).astype(np.float64))
+    tail = np.stack([np.zeros(8), np.zeros(8), img_ts[MVSEC_FIRST + n_items] + 1e-4 * np.arange(8), np.ones(8)], 1)
+    events = np.concatenate(rows + [tail], 0)          # MVSEC rows are (x, y, t, p)
+    inds = np.zeros(n_img, dtype=np.int64)
+    cum = np.concatenate([[0], np.cumsum(counts)])
+    inds[MVSEC_FIRST:MVSEC_FIRST + n_items + 1] = cum
+    inds[MVSEC_FIRST + n_items + 1:] = cum[-1]
+    yy, xx = np.mgrid[0:height, 0:width]
+
+    def frame(i):
+        return ((yy * 3 + xx * 5 + i * 7) % 256).astype(np.uint8)
+
+    n_flow = 12
+    flow_ts = (img_ts[MVSEC_FIRST] - 0.013 + 0.05 * np.arange(n_flow + 1)).astype(np.float64)
+
+    def flow(j):
+        f = np.stack([2.0 * np.sin(0.05 * xx + 0.3 * j) + 0.01 * yy, 1.5 * np.cos(0.04 * yy - 0.2 * j)]).astype(np.float64)
+        f[:, 40:60, 100:140] = 0.0                     # no ground truth here
+        f[0, 200:210, 300:320] = 5000.0                # beyond the |flow| < 1000 validity bound
+        return f
+
+    data = _Mapping({'davis/left/events': _ArrayDataset(events), 'davis/left/image_raw': _LazyDataset(n_img, frame, np.uint8),
+                     'davis/left/image_raw_ts': _ArrayDataset(img_ts), 'davis/left/image_raw_event_inds': _ArrayDataset(inds)})
+    gt = _Mapping({'davis/left/flow_dist': _LazyDataset(n_flow, flow, np.float64), 'davis/left/flow_dist_ts': _ArrayDataset(flow_ts)})
+    return data, gt

@@ -361,6 +361,93 @@ def run_readers(name):
     print(name, {k: v.shape for k, v in out.items()})
 
 
+def run_readers_r3(name):
+    """Round 3, f-4 remainder: (a) VR.update_event_frame_flow_pack (video_readers.py:237-282, what test_with_flow.py:121 calls)
+    on the synthetic event file of run_readers; (b) the reference's MVSEC_NE dataset (data_readers/MVSEC.py:292-543) on a
+    synthetic in-memory sequence (tests/weights_util.py::synth_mvsec_source) -- h5py is absent, so a stub module whose
+    File() hands out that source stands in for it (the class itself is the reference's, unmodified); items whose image
+    interval lies inside one ground-truth flow interval only (the other branch needs cv2.remap)."""
+    import tempfile
+    import data_readers.event_readers as ref_er          # noqa: E402
+    import data_readers.video_readers as ref_vr          # noqa: E402
+    from weights_util import synth_event_file, synth_mvsec_source, MVSEC_SPLIT
+    W, H, bins = 36, 28, 5
+    d = tempfile.mkdtemp()
+    out = {"meta": np.array([6, 6000, W, H, bins], dtype=np.int64)}
+    path3 = os.path.join(d, "events_in.txt")
+    synth_event_file(path3, seed=6, n=6000, width=W, height=H, duration=0.5, overshoot=False)
+    with open(path3) as f:
+        lines = f.readlines()[1:]
+    with open(path3, "w") as g:
+        g.writelines(lines)
+    T = list(np.linspace(0.01, 0.49, 13))
+    out["T_image"] = np.array(T)
+
+    class Fake(ref_vr.VR):
+        def start(self, reader, n):
+            self.r = iter(reader)
+            self.num_frames = n
+            self.frame_id = 0
+
+        def update_frame(self):
+            self.frame_id += 1
+            return np.full((self.height, self.width), self.frame_id % 250, np.uint8), 0
+
+        def update_flow(self, prev, cur):
+            return np.full((2, self.height, self.width), float(cur[0, 0]) - 0.5 * float(prev[0, 0]), np.float32)
+
+        def update_events(self):
+            try:
+                return np.asarray(next(self.r), dtype=np.float64)
+            except StopIteration:
+                return None
+
+    vr = Fake([H, W], num_bins=bins)
+    vr.start(ref_er.RefTimeEventReaderZip(path3, T), len(T))
+    grids, calls = [], []
+    for _ in range(40):
+        if vr.ending or vr.frame_id >= vr.num_frames:
+            break
+        ev, pack, gt, flows = vr.update_event_frame_flow_pack()
+        grids += [np.asarray(e, dtype=np.float32) for e in ev]
+        calls.append([len(ev), len(pack), vr.num_events, int(gt[0, 0]), int(pack[0][0, 0]), len(flows), float(flows[0][0, 0, 0])])
+    out["flowpack_grids"] = np.stack(grids)
+    out["flowpack_calls"] = np.array(calls, dtype=np.float64)
+
+    # ---- (b) MVSEC_NE ----
+    data, gt = synth_mvsec_source(seed=3)
+    h5 = types.ModuleType("h5py")
+    h5.File = lambda path, mode="r": data if path.endswith("_data.hdf5") else gt
+    sys.modules["h5py"] = h5
+    import data_readers.MVSEC as ref_mv                  # noqa: E402  (cv2 is already stubbed; MVSEC_utils imports it)
+    for suffix in ("_data.hdf5", "_gt.hdf5"):
+        open(os.path.join(d, MVSEC_SPLIT + suffix), "w").close()
+    a = argparse.Namespace(num_events=2000, num_bins=5)
+    ds = ref_mv.MVSEC_NE(a, data_root=d, data_split=MVSEC_SPLIT)
+    out["mv_len"] = np.array([len(ds), ds.raw_index_shift, ds.raw_index_max, ds.skip_num], dtype=np.int64)
+    val = ref_mv.MVSEC_NE(argparse.Namespace(num_events=2000, num_bins=5), data_root=d, data_split=MVSEC_SPLIT, data_mode='val')
+    out["mv_val_index"] = np.array([len(val)] + val.INDEX_MAP[:24], dtype=np.int64)
+    items = [0, 2, 3, 5, 8]
+    out["mv_items"] = np.array(items, dtype=np.int64)
+    for it in items:
+        raw_list, batch = ds[it]
+        out["mv%d_windows" % it] = np.array([[n, w[0, 0], w[-1, 0], w[:, 1].sum(), w[:, 2].sum(), w[:, 3].sum()] for w, n in raw_list],
+                                            dtype=np.float64)
+        out["mv%d_img0" % it] = batch["gt_img0"][:, ::7, ::9].numpy()
+        out["mv%d_img1" % it] = batch["gt_img1"][:, ::7, ::9].numpy()
+        out["mv%d_flow" % it] = batch["gt_flow"][:, ::5, ::6].numpy()
+        out["mv%d_valid" % it] = np.array([float(batch["flow_valid"].sum()), batch["flow_valid"].shape[1], batch["flow_valid"].shape[2],
+                                           batch["org_width"], batch["org_height"]], dtype=np.float64)
+        evs = ds.events_to_voxel(raw_list[0][0], 260, 346)
+        out["mv%d_vox" % it] = evs[0, :, 60:100, 100:160].numpy()
+        out["mv%d_voxstat" % it] = np.array([float(evs.double().sum()), float(evs.double().abs().sum()), float((evs != 0).sum())] + list(evs.shape),
+                                            dtype=np.float64)
+        assert len(ds.get_raw_events(it)) == sum(n for _, n in raw_list)
+    del sys.modules["h5py"]
+    np.savez_compressed(os.path.join(GOLD, name), **out)
+    print(name, {k: v.shape for k, v in out.items()})
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ref_model, ref_flow = import_reference()
@@ -382,6 +469,9 @@ def main():
         run_fullstate(ref_model, 100, 124, 2, 4, 21, "eiflow_100x124_fullstate.npz")
         run_readers("readers.npz")
         return
+    if "--only-r3" in sys.argv:        # round 3 additions only (earlier fixtures stay byte-identical)
+        run_r3(ref_model)
+        return
     if "--only-readers" in sys.argv:
         run_readers("readers.npz")
         return
@@ -399,6 +489,11 @@ def main():
     run_metrics("metrics.npz")
     run_fullstate(ref_model, 100, 124, 2, 4, 21, "eiflow_100x124_fullstate.npz")
     run_readers("readers.npz")
+    run_r3(ref_model)
+
+
+def run_r3(ref_model):
+    run_readers_r3("readers_r3.npz")
 
 
 if __name__ == "__main__":
