@@ -2038,6 +2038,10 @@ extern "C" int cf_metrics_fwl(const float* voxel, const float* flow, int B, int 
     return launch_metrics_fwl(voxel, flow, B, C, H, W, out3, scratch, static_cast<hipStream_t>(stream)) == hipSuccess ? CF_OK : CF_ERR_HIP;
 }
 
+extern "C" int cf_metrics_ssim(const float* rec, const float* tgt, int planes, int H, int W, double* out2, double* scratch, void* stream) {
+    return launch_metrics_ssim(rec, tgt, planes, H, W, out2, scratch, static_cast<hipStream_t>(stream)) == hipSuccess ? CF_OK : CF_ERR_HIP;
+}
+
 extern "C" int cf_events_to_voxel(const double* events, const int64_t* offsets, int B, int bins, int H, int W, float* voxel,
                                   double* stats_scratch, int normalize, void* stream) {
     static_assert(sizeof(long) == sizeof(int64_t), "LP64");

@@ -245,4 +245,8 @@ hipError_t launch_metrics_flow(const float* flow, const float* gt, const float* 
 hipError_t launch_metrics_fwl(const float* voxel, const float* flow, int B, int C, int H, int W, double* out, double* scratch,
                               hipStream_t s);
 
+// out[2] = {ssim, cs}: pytorch_msssim.SSIM(data_range=1, win 11, sigma 1.5, K (0.01, 0.03), size_average) over `planes` images of
+// H x W (loss.py:314,319); H, W >= 11
+hipError_t launch_metrics_ssim(const float* x, const float* y, int planes, int H, int W, double* out, double* scratch, hipStream_t s);
+
 }  // namespace cf

@@ -5,8 +5,10 @@
 //   cf_metrics_flow    FlowL1LossDict.evaluate: photo_loss, epe, 1/3/5 px outliers, `out`    loss.py:237-265
 //   cf_metrics_fwl     voxel_warping_flow_loss (flow-warp loss, FWL) for the flow and for zero flow   loss.py:27-83,
 //                      test_wo_flow.py:161
-// SSIM and LPIPS (pytorch_msssim / lpips + torchvision weights) are third-party packages that are not installed here
-// and are not restated.
+//   cf_metrics_ssim    ReconLoss.evaluate's 'ssim' = pytorch_msssim.SSIM(data_range=1, channel=1): 11-tap gaussian (sigma 1.5),
+//                      valid convolution, K = (0.01, 0.03).  The package is absent offline; the kernel follows its published
+//                      algorithm (restated in oracle/cista_oracle.py::ssim) -- parity UNPINNED by the reference for this metric.
+// LPIPS (lpips + torchvision AlexNet weights from the network) is not restated.
 //
 // Every kernel writes one partial-sum row per workgroup and a one-workgroup fold kernel adds the rows in a fixed
 // order in fp64: deterministic, and more accurate than the fp32 tree sums of torch.mean (results agree with the
@@ -48,6 +50,9 @@ __global__ __launch_bounds__(256) void met_fold_kernel(const double* __restrict_
         const double mse = s[0] / n;
         out[0] = mse;
         out[1] = mse < 1.0e-10 ? 100.0 : 20.0 * log10(1.0 / sqrt(mse));      // PSNR(data_range=1), loss.py:20-24
+    } else if (kind == 3) {
+        out[0] = s[0] / n;          // mean of the SSIM map over every plane's valid window positions
+        out[1] = s[1] / n;          // mean of the contrast-structure map (pytorch_msssim's `cs`)
     } else if (kind == 1) {
         // s: 0 photo sum, 1 #valid, 2 epe sum, 3 #(epe>1), 4 #(epe>3), 5 #(epe>5), 6 #out   (over valid > 0)
         const double nv = s[1];
@@ -171,6 +176,75 @@ __global__ __launch_bounds__(256) void met_fwl_kernel(const float* __restrict__ 
     }
 }
 
+// ---- SSIM (pytorch_msssim._ssim): separable 11-tap gaussian, H direction first, then W, 'valid' (no padding) ----
+struct SsimWin { float g[11]; };
+static constexpr int SS_TY = 16, SS_TX = 64;                  // output tile of a workgroup
+static constexpr int SS_IY = SS_TY + 10, SS_IX = SS_TX + 10;  // input tile
+
+__global__ __launch_bounds__(256) void met_ssim_kernel(const float* __restrict__ X, const float* __restrict__ Y, int planes, int H,
+                                                       int W, SsimWin win, float C1, float C2, double* __restrict__ partial) {
+    __shared__ float sX[SS_IY][SS_IX], sY[SS_IY][SS_IX];
+    __shared__ float sV[5][SS_TY][SS_IX + 1];
+    __shared__ double sh[4 * 2];
+    const int Ho = H - 10, Wo = W - 10;
+    const int nty = (Ho + SS_TY - 1) / SS_TY, ntx = (Wo + SS_TX - 1) / SS_TX;
+    const long ntiles = (long)planes * nty * ntx;
+    double s[2] = {0.0, 0.0};
+    for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int pl = (int)(t / (nty * ntx));
+        const int r = (int)(t - (long)pl * nty * ntx);
+        const int oy0 = (r / ntx) * SS_TY, ox0 = (r % ntx) * SS_TX;
+        const float* xp = X + (long)pl * H * W;
+        const float* yp = Y + (long)pl * H * W;
+        __syncthreads();                                      // the previous tile's passes are done with the buffers
+        for (int i = threadIdx.x; i < SS_IY * SS_IX; i += 256) {
+            const int iy = i / SS_IX, ix = i - iy * SS_IX;
+            const int gy = oy0 + iy, gx = ox0 + ix;
+            const bool ok = gy < H && gx < W;
+            sX[iy][ix] = ok ? xp[(long)gy * W + gx] : 0.f;
+            sY[iy][ix] = ok ? yp[(long)gy * W + gx] : 0.f;
+        }
+        __syncthreads();
+        // H direction: the five filtered quantities x, y, x*x, y*y, x*y at (output row, input column)
+        for (int i = threadIdx.x; i < SS_TY * SS_IX; i += 256) {
+            const int oy = i / SS_IX, ix = i - oy * SS_IX;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                const float x = sX[oy + k][ix], y = sY[oy + k][ix], g = win.g[k];
+                a0 += g * x; a1 += g * y; a2 += g * (x * x); a3 += g * (y * y); a4 += g * (x * y);
+            }
+            sV[0][oy][ix] = a0; sV[1][oy][ix] = a1; sV[2][oy][ix] = a2; sV[3][oy][ix] = a3; sV[4][oy][ix] = a4;
+        }
+        __syncthreads();
+        // W direction + the SSIM expression
+        for (int i = threadIdx.x; i < SS_TY * SS_TX; i += 256) {
+            const int oy = i / SS_TX, ox = i - oy * SS_TX;
+            if (oy0 + oy >= Ho || ox0 + ox >= Wo) continue;
+            float m1 = 0.f, m2 = 0.f, xx = 0.f, yy = 0.f, xy = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                const float g = win.g[k];
+                m1 += g * sV[0][oy][ox + k]; m2 += g * sV[1][oy][ox + k]; xx += g * sV[2][oy][ox + k];
+                yy += g * sV[3][oy][ox + k]; xy += g * sV[4][oy][ox + k];
+            }
+            const float m1s = m1 * m1, m2s = m2 * m2, m12 = m1 * m2;
+            const float s1 = xx - m1s, s2 = yy - m2s, s12 = xy - m12;
+            const float cs = (2.f * s12 + C2) / (s1 + s2 + C2);
+            const float v = ((2.f * m12 + C1) / (m1s + m2s + C1)) * cs;
+            s[0] += (double)v;
+            s[1] += (double)cs;
+        }
+    }
+    block_sum_256<2>(s, sh);
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x * 8 + 0] = s[0];
+        partial[blockIdx.x * 8 + 1] = s[1];
+#pragma unroll
+        for (int k = 2; k < 8; ++k) partial[blockIdx.x * 8 + k] = 0.0;
+    }
+}
+
 static int met_blocks(long n) {
     long b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > MET_BLOCKS ? MET_BLOCKS : b));
@@ -206,6 +280,25 @@ hipError_t launch_metrics_fwl(const float* voxel, const float* flow, int B, int 
     note_launch("met_fwl_kernel", dim3(nb), dim3(256));
     hipLaunchKernelGGL(met_fwl_kernel, dim3(nb), dim3(256), 0, s, voxel, flow, B, C, H, W, scratch);
     hipLaunchKernelGGL(met_fold_kernel, dim3(1), dim3(256), 0, s, scratch, nb, 2, (double)n, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_metrics_ssim(const float* x, const float* y, int planes, int H, int W, double* out, double* scratch, hipStream_t s) {
+    if (!x || !y || !out || !scratch || planes <= 0 || H < 11 || W < 11) return hipErrorInvalidValue;
+    SsimWin win;
+    float sum = 0.f;
+    for (int k = 0; k < 11; ++k) {          // pytorch_msssim._fspecial_gauss_1d(11, 1.5) in fp32
+        const float c = (float)(k - 5);
+        win.g[k] = expf(-(c * c) / (2.f * 1.5f * 1.5f));
+        sum += win.g[k];
+    }
+    for (int k = 0; k < 11; ++k) win.g[k] /= sum;
+    const long tiles = (long)planes * ((H - 10 + SS_TY - 1) / SS_TY) * ((W - 10 + SS_TX - 1) / SS_TX);
+    const int nb = (int)(tiles < MET_BLOCKS ? tiles : MET_BLOCKS);
+    const float C1 = (0.01f * 1.f) * (0.01f * 1.f), C2 = (0.03f * 1.f) * (0.03f * 1.f);
+    note_launch("met_ssim_kernel", dim3(nb), dim3(256));
+    hipLaunchKernelGGL(met_ssim_kernel, dim3(nb), dim3(256), 0, s, x, y, planes, H, W, win, C1, C2, scratch);
+    hipLaunchKernelGGL(met_fold_kernel, dim3(1), dim3(256), 0, s, scratch, nb, 3, (double)planes * (H - 10) * (W - 10), out);
     return hipGetLastError();
 }
 

@@ -21,7 +21,7 @@ SYMBOLS = [
     "cf_op_conv2d", "cf_op_instance_norm_relu", "cf_op_corr_lookup", "cf_op_nchw_to_nhwc",
     "cf_op_nhwc_to_nchw", "cf_profile_enable", "cf_profile_read", "cf_conv_tile_name", "cf_profile_report", "cf_op_conv2d_bench", "cf_events_to_voxel", "cf_op_conv2d_inorm_stats", "cf_quantize_u8", "cf_hint_prev_grid",
     "cf_profile_report_json", "cf_metrics_scratch_doubles", "cf_metrics_recon", "cf_metrics_flow", "cf_metrics_fwl",
-    "cf_graph_enable", "cf_graph_stats", "cf_events_to_voxel_ex", "cf_voxel_preprocess",
+    "cf_graph_enable", "cf_graph_stats", "cf_events_to_voxel_ex", "cf_voxel_preprocess", "cf_metrics_ssim",
 ]
 
 
@@ -101,6 +101,8 @@ def load():
     lib.cf_metrics_flow.restype = i
     lib.cf_metrics_fwl.argtypes = [fp, fp, i, i, i, i, fp, fp, vp]
     lib.cf_metrics_fwl.restype = i
+    lib.cf_metrics_ssim.argtypes = [fp, fp, i, i, i, fp, fp, vp]
+    lib.cf_metrics_ssim.restype = i
     lib.cf_graph_enable.argtypes = [vp, i]
     lib.cf_graph_enable.restype = i
     lib.cf_graph_stats.argtypes = [vp, C.POINTER(C.c_longlong)]

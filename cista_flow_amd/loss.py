@@ -5,8 +5,10 @@ Same class / function names and return conventions as the reference (`ReconLoss.
 `from loss import ReconLoss, voxel_warping_flow_loss` (test_wo_flow.py:20) can point here.  The arithmetic runs in
 csrc/metrics.hip; only a few doubles per frame cross PCIe.
 
-Not built: SSIM and LPIPS (`pytorch_msssim`, `lpips` + torchvision weights are third-party packages that are absent
-offline) -- `ReconLoss.evaluate` returns `mse` and `psnr` only -- and the training losses (`forward` methods).
+SSIM follows pytorch_msssim's published algorithm (the package is absent offline, so this one metric is UNPINNED by the
+reference; oracle/cista_oracle.py::ssim is the CPU restatement it is tested against).  Not built: LPIPS (`lpips` +
+torchvision AlexNet weights from the network) -- `ReconLoss.evaluate` returns `mse`, `psnr`, `ssim` -- and the training
+losses (`forward` methods).
 """
 import torch
 import torch.nn as nn
@@ -39,6 +41,36 @@ def recon_metrics(rec_img, target_img):
     return out
 
 
+def ssim_metrics(rec_img, target_img):
+    """-> float64 CUDA tensor [2] = (ssim, cs) of pytorch_msssim.SSIM(data_range=1, size_average=True); asynchronous."""
+    _lib.check_f32_cuda(rec_img, "rec_img")
+    _lib.check_f32_cuda(target_img, "target_img", tuple(rec_img.shape))
+    if rec_img.dim() != 4 or rec_img.shape[2] < 11 or rec_img.shape[3] < 11:
+        raise ValueError("ssim: expected [B,C,H,W] with H, W >= 11 (the 11-tap gaussian window is applied without padding)")
+    a, b = rec_img.contiguous(), target_img.contiguous()
+    dev = a.device
+    out = torch.empty(2, dtype=torch.float64, device=dev)
+    scratch = _scratch(dev)
+    L = _lib.load()
+    with torch.cuda.device(dev):
+        _check(L.cf_metrics_ssim(_lib.ptr(a), _lib.ptr(b), a.shape[0] * a.shape[1], a.shape[2], a.shape[3], _lib.ptr(out),
+                                 _lib.ptr(scratch), _lib.current_stream_ptr(dev)), "cf_metrics_ssim")
+    return out
+
+
+class SSIM(nn.Module):
+    """pytorch_msssim.SSIM as loss.py:314 builds it (data_range=1, size_average=True, win 11 / sigma 1.5, K (0.01, 0.03))."""
+
+    def __init__(self, data_range=1, size_average=True, channel=1, nonnegative_ssim=False):
+        super().__init__()
+        if data_range != 1 or not size_average or nonnegative_ssim:
+            raise NotImplementedError("SSIM: only the configuration CISTA-Flow uses (data_range=1, size_average=True)")
+        self.channel = channel
+
+    def forward(self, X, Y):
+        return ssim_metrics(X, Y)[0].float()
+
+
 class PSNR(nn.Module):
     """loss.py:15-24 (data_range 1 only, as ReconLoss builds it)."""
 
@@ -53,16 +85,17 @@ class PSNR(nn.Module):
 
 
 class ReconLoss(nn.Module):
-    """ReconLoss.evaluate (loss.py:316-328) without its third-party half (ssim, lpips)."""
+    """ReconLoss.evaluate (loss.py:316-328) without 'lpips' (needs network weights)."""
 
     def __init__(self, frame_warper=None, lpips_net='alex'):
         super().__init__()
         self.warp_fn = frame_warper
         self.psnr_fn = PSNR(data_range=1)
+        self.ssim_loss_fn = SSIM(data_range=1, size_average=True, channel=1, nonnegative_ssim=False)
 
     def evaluate(self, rec_img, target_img):
-        m = recon_metrics(rec_img, target_img).cpu()
-        return {'mse': float(m[0]), 'psnr': float(m[1])}
+        m = torch.cat([recon_metrics(rec_img, target_img), ssim_metrics(rec_img, target_img)]).cpu()   # ONE device -> host copy
+        return {'mse': float(m[0]), 'psnr': float(m[1]), 'ssim': float(m[2])}
 
     def forward(self, *a, **k):
         raise NotImplementedError("training loss (loss.py:331-360) is out of scope of the inference hot path")

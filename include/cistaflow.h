@@ -149,7 +149,12 @@ int cf_quantize_u8(const float* img, unsigned char* out, long long n, void* stre
  * `stream`; every result is written to DEVICE doubles (`out*`), so a caller reads a frame's scores with one small copy
  * whenever it wants them.  scratch: cf_metrics_scratch_doubles() device doubles.  Deterministic (fixed-order fp64 folds).
  *   cf_metrics_recon  out2 = {mse, psnr}: nn.MSELoss and PSNR(data_range=1) of ReconLoss.evaluate (loss.py:15-24,316-328;
- *                     psnr = 100 when mse < 1e-10).  SSIM / LPIPS need pytorch_msssim / lpips (third-party, absent): not built.
+ *                     psnr = 100 when mse < 1e-10).
+ *   cf_metrics_ssim   out2 = {ssim, cs}: ReconLoss.evaluate's 'ssim' = pytorch_msssim.SSIM(data_range=1, size_average=True,
+ *                     channel=1) (loss.py:314,319): 11-tap gaussian window (sigma 1.5), 'valid' convolution, K = (0.01, 0.03),
+ *                     mean over all window positions of all `planes` = B*C images of H x W (H, W >= 11).  The package is not
+ *                     installed offline: this follows its published algorithm (UNPINNED by the reference).  LPIPS needs
+ *                     network weights (lpips + torchvision): not built.
  *   cf_metrics_flow   out6 = {photo_loss, epe, 1px, 3px, 5px, out}: FlowL1LossDict.evaluate (loss.py:237-265).  flow,
  *                     gt_flow NCHW [B][2][H][W]; gt_img0/1 [B][1][H][W]; flow_valid [B][1][H][W] or NULL (then
  *                     exp(-50*(warp(gt_img0, gt_flow) - gt_img1)^2), loss.py:241); warp_mode = the FrameWarp mode;
@@ -164,6 +169,7 @@ int cf_metrics_flow(const float* flow, const float* gt_flow, const float* gt_img
                     double* scratch, void* stream);
 int cf_metrics_fwl(const float* voxel, const float* flow, int B, int C, int H, int W, double* out3, double* scratch,
                    void* stream);
+int cf_metrics_ssim(const float* rec, const float* target, int planes, int H, int W, double* out2, double* scratch, void* stream);
 
 /* measurement: when enabled, EVERY kernel launch of the fused paths (convolutions and the HBM-class kernels: warp,
  * up-sampling, InstanceNorm apply, correlation lookup / pyramid, flow up-sampling ...) is bracketed by HIP events on

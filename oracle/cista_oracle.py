@@ -664,3 +664,29 @@ def voxel_warping_flow_loss(voxel, displacement):
         iy = ((gy + 1.0) / 2.0) * (H - 1)
         acc = acc + fwl_sample_zeros(voxel[:, i], ix, iy)
     return float(acc.double().var())
+
+
+def ssim(X, Y, data_range=1.0, win_size=11, win_sigma=1.5, K=(0.01, 0.03), dtype=torch.float32):
+    """pytorch_msssim.ssim / SSIM(data_range=1, size_average=True, nonnegative_ssim=False) as ReconLoss builds it
+    (loss.py:314,319).  The package (third-party dependency of the reference, no version pinned by it; algorithm of
+    pytorch_msssim >= 0.2: ssim.py::_fspecial_gauss_1d, gaussian_filter, _ssim) is NOT installed offline, so this is a
+    restatement of its published algorithm: 1-D gaussian window, separable 'valid' convolution (H direction first, then W),
+    C1 = (K1 L)^2, C2 = (K2 L)^2, mean of the SSIM map over the valid positions of every (b, c) plane, then over planes.
+    Parity for this metric is therefore unpinned by the reference.  Returns (ssim, cs) as Python floats."""
+    X, Y = X.to(dtype), Y.to(dtype)
+    coords = torch.arange(win_size, dtype=torch.float32) - win_size // 2
+    g = torch.exp(-(coords ** 2) / (2 * win_sigma ** 2))
+    g = (g / g.sum()).to(dtype)
+    C = X.shape[1]
+
+    def gauss(t):
+        t = F.conv2d(t, g.view(1, 1, -1, 1).repeat(C, 1, 1, 1), groups=C)
+        return F.conv2d(t, g.view(1, 1, 1, -1).repeat(C, 1, 1, 1), groups=C)
+
+    C1, C2 = (K[0] * data_range) ** 2, (K[1] * data_range) ** 2
+    mu1, mu2 = gauss(X), gauss(Y)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1 * mu1, mu2 * mu2, mu1 * mu2
+    s1, s2, s12 = gauss(X * X) - mu1_sq, gauss(Y * Y) - mu2_sq, gauss(X * Y) - mu1_mu2
+    cs_map = (2 * s12 + C2) / (s1 + s2 + C2)
+    ssim_map = ((2 * mu1_mu2 + C1) / (mu1_sq + mu2_sq + C1)) * cs_map
+    return float(ssim_map.flatten(2).mean(-1).mean()), float(cs_map.flatten(2).mean(-1).mean())

@@ -25,7 +25,7 @@ def test_recon_metrics_golden(gpu):
     g = gu.load("metrics.npz")
     rec, tgt = torch.from_numpy(g["rec"]).to(gpu), torch.from_numpy(g["tgt"]).to(gpu)
     m = ReconLoss(None).evaluate(rec, tgt)
-    assert set(m) == {"mse", "psnr"}
+    assert set(m) == {"mse", "psnr", "ssim"}          # 'lpips' needs network weights: not built
     assert close(m["mse"], g["mse"]) and abs(m["psnr"] - float(g["psnr"])) < 1e-4
     assert float(PSNR()(rec, rec)) == 100.0 == float(g["psnr_same"])
 
@@ -106,3 +106,26 @@ def test_metrics_noncontiguous_inputs(gpu):
                                                            flow.clone(memory_format=torch.contiguous_format)))
     assert torch.equal(recon_metrics(i0, i1), recon_metrics(i0.clone(memory_format=torch.contiguous_format),
                                                             i1.clone(memory_format=torch.contiguous_format)))
+
+
+def test_ssim_vs_oracle(gpu):
+    """ReconLoss.evaluate's 'ssim' (pytorch_msssim.SSIM, data_range 1): the HIP kernel against the CPU restatement of the
+    package's algorithm (oracle.ssim; fp32 like the package, and fp64) -- the package itself is absent offline, so this metric is
+    unpinned by the reference.  Ragged sizes (tile edges), the minimum 11 x 11 image, several planes, identical images = 1."""
+    from cista_flow_amd.loss import ReconLoss, SSIM, ssim_metrics
+    from oracle import cista_oracle as orc
+    gen = torch.Generator().manual_seed(21)
+    for (B, C, H, W) in ((1, 1, 180, 240), (3, 1, 67, 93), (2, 2, 11, 11), (1, 1, 27, 140)):
+        X = torch.rand(B, C, H, W, generator=gen)
+        Y = (X + 0.08 * torch.randn(B, C, H, W, generator=gen)).clamp(0, 1)
+        got = ssim_metrics(X.to(gpu), Y.to(gpu)).cpu()
+        r32, r64 = orc.ssim(X, Y), orc.ssim(X, Y, dtype=torch.float64)
+        assert abs(float(got[0]) - r64[0]) < 2e-5 and abs(float(got[1]) - r64[1]) < 2e-5, ((B, C, H, W), got, r64)
+        assert abs(float(got[0]) - r32[0]) < 2e-5
+        assert torch.equal(got, ssim_metrics(X.to(gpu), Y.to(gpu)).cpu())          # deterministic
+        assert abs(float(ssim_metrics(X.to(gpu), X.to(gpu))[0]) - 1.0) < 1e-6
+    X, Y = torch.rand(2, 1, 64, 80, generator=gen), torch.rand(2, 1, 64, 80, generator=gen)
+    m = ReconLoss(None).evaluate(X.to(gpu), Y.to(gpu))
+    assert abs(m["ssim"] - orc.ssim(X, Y)[0]) < 2e-5 and abs(float(SSIM()(X.to(gpu), Y.to(gpu))) - m["ssim"]) < 1e-6
+    with pytest.raises(ValueError):
+        ssim_metrics(torch.zeros(1, 1, 10, 40, device=gpu), torch.zeros(1, 1, 10, 40, device=gpu))
