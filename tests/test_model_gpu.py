@@ -378,6 +378,7 @@ def test_full_size_batch_properties(gpu, kind, H, W, B, prec):
     sd = {k: v.cpu() for k, v in m.state_dict().items()}
     with torch.no_grad():
         O = _oracle_drive(kind, sd, ev0, old0)
+        O1 = _oracle_drive(kind, sd, ev1, old1)          # the LAST slot of the mixed batch holds a different sequence
     tol = TOL if prec == "f32" else 1e-2
     for t in range(2):
         for name, got, ref in (("I", A[t][0], O[t][0]), ("flow", A[t][1], O[t][1]), ("z", A[t][2], O[t][2]), ("h", A[t][3], O[t][3])):
@@ -385,6 +386,34 @@ def test_full_size_batch_properties(gpu, kind, H, W, B, prec):
         assert len(A[t][4]) == len(O[t][4])
         for a, b in zip(A[t][4], O[t][4]):
             assert gu.rel_err(a[:1].cpu(), b) < tol, t
+        # slot B-1 of the mixed batch (a last-slot indexing error cannot hide behind slot 0)
+        for name, got, ref in (("I", Bo[t][0], O1[t][0]), ("flow", Bo[t][1], O1[t][1]), ("z", Bo[t][2], O1[t][2]), ("h", Bo[t][3], O1[t][3])):
+            assert gu.rel_err(got[B - 1:].cpu(), ref) < tol, (t, name, "last slot")
+
+
+@pytest.mark.parametrize("name,kind", [("eraft_180x240.npz", "eraft"), ("eiflow_480x640.npz", "eiflow")])
+def test_fullsize_reference_goldens(gpu, name, kind):
+    """The HIP path against fixtures the REFERENCE produced at the full size of BASELINE configs[2] (eraft 180x240) and
+    configs[3] (eiflow 480x640): B = 1, two recurrent frames, strided probes of every output and state (round 3)."""
+    from test_oracle_golden import fullsize_probe
+    g = gu.load(name)
+    H, W, B, frames, seed = [int(v) for v in g["meta"][:5]]
+    m = _build(kind, H, W, seed, gpu)
+    states, prev = None, torch.zeros(B, 1, H, W, device=gpu)
+    old = wu.synth_events(B, 5, H, W, seed * 1000 + 999).to(gpu)
+    with torch.no_grad():
+        for t in range(frames):
+            ev = wu.synth_events(B, 5, H, W, seed * 1000 + t).to(gpu)
+            data = {"event_voxel": ev, "rec_img0": prev}
+            if kind == "eraft":
+                data["event_voxel_old"] = old
+            I, bf, states = m(data, states, {})
+            old = ev
+            st = [states[0].cpu(), states[1].cpu(), (states[2][0].cpu(), states[2][1].cpu())]
+            bfc = {"flow_final": bf["flow_final"].cpu(), "flow_init": bf["flow_init"].cpu(), "flow_preds": [bf["flow_preds"][0].cpu()]}
+            for nm, got, ref in fullsize_probe(g, t, I.cpu(), bfc, st):
+                assert gu.rel_err(got, ref) < TOL, (t, nm)
+            prev = I.clone()
 
 
 def test_eiflow_fullstate_golden(gpu):

@@ -175,3 +175,36 @@ def test_fullstate_golden():
         prev = I.clone()
     assert gu.rel_err(states[1], g["z_full"]) < 5e-5
     assert gu.rel_err(states[2][0], g["h_full"]) < 5e-5
+
+
+FULLSIZE = [("eraft_180x240.npz", "eraft"), ("eiflow_480x640.npz", "eiflow")]
+
+
+def fullsize_probe(g, t, I, bf, states):
+    """(name, got, ref) triples of one frame of a tools/gen_golden.py::run_fullsize fixture (strided probes)."""
+    st, cs = int(g["meta"][5]), int(g["meta"][6])
+    return [("I", I[..., ::st, ::st], g["I_%d" % t]), ("flow", bf["flow_final"][..., ::st, ::st], g["flow_%d" % t]),
+            ("flowlow", bf["flow_init"], g["flowlow_%d" % t]), ("preds0", bf["flow_preds"][0][..., ::2 * st, ::2 * st], g["preds0_%d" % t]),
+            ("c", gu.sub(states[0], cs, 2 * st, 2 * st), g["c_%d" % t]), ("z", gu.sub(states[1], cs, 2 * st, 2 * st), g["z_%d" % t]),
+            ("h", gu.sub(states[2][0], cs, 2 * st, 2 * st), g["h_%d" % t]), ("cc", gu.sub(states[2][1], cs, 2 * st, 2 * st), g["cc_%d" % t])]
+
+
+@pytest.mark.parametrize("name,kind", FULLSIZE)
+def test_fullsize_reference_goldens(name, kind):
+    """The oracle against reference-run fixtures at the full size of BASELINE configs[2] (eraft 180x240) and configs[3]
+    (eiflow 480x640), B = 1, two recurrent frames (round 3)."""
+    g = gu.load(name)
+    H, W, B, frames, seed = [int(v) for v in g["meta"][:5]]
+    sd = wu.make_state_dict(gu.layout("%s_state_dict_layout.json" % kind), seed)
+    states, prev, old = None, torch.zeros(B, 1, H, W), wu.synth_events(B, 5, H, W, seed * 1000 + 999)
+    for t in range(frames):
+        ev = wu.synth_events(B, 5, H, W, seed * 1000 + t)
+        if kind == "eraft":
+            I, bf, states = orc.eraft_step(sd, {"event_voxel": ev, "event_voxel_old": old, "rec_img0": prev}, states)
+        else:
+            I, bf, states = orc.eiflow_step(sd, {"event_voxel": ev, "rec_img0": prev}, states)
+        old = ev
+        for nm, got, ref in fullsize_probe(g, t, I, bf, states):
+            # 1e-4: the first iteration's flow at 480x640 (small values, 4800-pixel correlation rows) sits at 5.4e-5 of its scale
+            assert gu.rel_err(got, ref) < 1e-4, (t, nm)
+        prev = I.clone()

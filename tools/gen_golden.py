@@ -492,8 +492,42 @@ def main():
     run_r3(ref_model)
 
 
+def run_fullsize(ref_model, kind, H, W, frames, seed, name, st, cs):
+    """Round 3: reference-run fixtures at the FULL size of the two BASELINE configs that had none (eraft 180x240 = configs[2],
+    eiflow 480x640 = configs[3]), B = 1, the drivers' loop of test_with_flow.py:120-156.  Only strided probes are kept
+    (outputs every `st`-th pixel, states every `cs`-th channel / 2*st-th pixel; the inputs are regenerated from the seed)."""
+    from weights_util import fill_module, synth_events
+    torch.manual_seed(0)
+    model = (ref_model.ERAFTCistaNet if kind == "eraft" else ref_model.DCEIFlowCistaNet)(ns(H, W)).eval()
+    fill_module(model, seed)
+    out = {"meta": np.array([H, W, 1, frames, seed, st, cs], dtype=np.int64)}
+    states, prev = None, torch.zeros(1, 1, H, W)
+    evs_old = synth_events(1, 5, H, W, seed * 1000 + 999)
+    with torch.no_grad():
+        for t in range(frames):
+            ev = synth_events(1, 5, H, W, seed * 1000 + t)
+            data = {"event_voxel": ev, "rec_img0": prev}
+            if kind == "eraft":
+                data["event_voxel_old"] = evs_old
+            I, bf, states = model(data, states, {})
+            evs_old = ev.clone()
+            out["I_%d" % t] = I[..., ::st, ::st].contiguous().numpy()
+            out["flow_%d" % t] = bf["flow_final"][..., ::st, ::st].contiguous().numpy()
+            out["flowlow_%d" % t] = bf["flow_init"].numpy()
+            out["preds0_%d" % t] = bf["flow_preds"][0][..., ::2 * st, ::2 * st].contiguous().numpy()
+            out["c_%d" % t] = sub(states[0], cs, 2 * st, 2 * st)
+            out["z_%d" % t] = sub(states[1], cs, 2 * st, 2 * st)
+            out["h_%d" % t] = sub(states[2][0], cs, 2 * st, 2 * st)
+            out["cc_%d" % t] = sub(states[2][1], cs, 2 * st, 2 * st)
+            prev = I.clone()
+    np.savez_compressed(os.path.join(GOLD, name), **out)
+    print(name, {k: v.shape for k, v in out.items() if k.endswith("_0")}, os.path.getsize(os.path.join(GOLD, name)))
+
+
 def run_r3(ref_model):
     run_readers_r3("readers_r3.npz")
+    run_fullsize(ref_model, "eraft", 180, 240, 2, 51, "eraft_180x240.npz", 2, 4)
+    run_fullsize(ref_model, "eiflow", 480, 640, 2, 52, "eiflow_480x640.npz", 4, 8)
 
 
 if __name__ == "__main__":
