@@ -19,7 +19,7 @@
 
 namespace cf {
 long inorm_partial_doubles(int B, int HW, int C);
-long inorm_patch_doubles(int B, int HW, int C);
+long inorm_patch_doubles(int B, int Ho, int Wo, int C);
 }
 
 using namespace cf;
@@ -368,7 +368,7 @@ static void setup_buffers(cf_handle* H_) {
             s.enc[e].D = a.f(nb * P1 * 64);
             s.enc[e].stats = a.f(nb * 256 * 2);
             s.enc[e].stats2 = a.f(nb * 256 * 2);
-            s.enc[e].partial = reinterpret_cast<double*>(a.raw(sizeof(double) * (size_t)inorm_patch_doubles((int)nb, (int)P1, 128)));
+            s.enc[e].partial = reinterpret_cast<double*>(a.raw(sizeof(double) * (size_t)inorm_patch_doubles((int)nb, s.H1, s.W1, 128)));
         }
         // the pair's output [2B][N][256]: fmap1 | emap (eiflow), fnet(old grid) | fnet(new grid) (eraft)
         s.fpair = a.f(2 * B * N * 256);
@@ -1916,7 +1916,7 @@ static int op_conv2d_impl(const float* in, int B, int Cin, int H, int W, const f
     }
     TmpBuf part;
     if (stats_out) {   // fused InstanceNorm statistics
-        if (hipMalloc(&part.p, sizeof(double) * (size_t)inorm_patch_doubles(B, Ho * Wo, Cout)) != hipSuccess) return CF_ERR_HIP;
+        if (hipMalloc(&part.p, sizeof(double) * (size_t)inorm_patch_doubles(B, Ho, Wo, Cout)) != hipSuccess) return CF_ERR_HIP;
         p.st_partial = static_cast<double*>(part.p);
     }
     int tile_used = 0;

@@ -996,6 +996,13 @@ static bool stage_ok(const ConvParams& p, int ks) {
     return true;
 }
 static bool splitk_ok(const ConvParams& p, int wk) { return stage_ok(p, KC * wk); }
+// LDS-DMA kernels (conv_dma_kernel, conv_wino*_kernel) address a source image with 32-bit byte offsets through a buffer
+// resource of BUF_RECORDS bytes; beyond that the hardware range check would hand back zeros instead of failing
+static bool dma_range_ok(const ConvParams& p) {
+    for (int i = 0; i < p.nseg; ++i)
+        if ((long)p.Hin * p.Win * p.seg_ld[i] * 4L >= 0x7FFFFF00L) return false;
+    return true;
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // LDS-DMA variant (plain NHWC read, fp32 MFMA): the A / B stage tiles are written straight into LDS by
@@ -1965,9 +1972,12 @@ static bool wino_ok(const ConvParams& p) {
     if (p.a_mode != A_NHWC || (p.prec != 0 && p.prec != 3) || !p.w_wino || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.padT != 1 || p.padL != 1) return false;
     if (p.Ho != p.Hin || p.Wo != p.Win || p.Hin < 12 || p.Win < 12) return false;
     if (p.w_bs != 0 && p.w_div <= 1) return false;          // per-image matrices (correlation GEMM); weight groups are fine
-    for (int i = 0; i < p.nseg; ++i)
+    for (int i = 0; i < p.nseg; ++i) {
         if (p.seg_c[i] % WG_KC) return false;
-    return true;
+    }
+    // the raw patch is addressed with 32-bit byte offsets through a buffer resource: a larger image would read zeros past the
+    // range check instead of failing, so such a launch falls back to the direct kernels
+    return dma_range_ok(p);
 }
 
 static hipError_t launch_wino(const ConvParams& p, int batch, hipStream_t s) {
@@ -2368,7 +2378,7 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
         if (tile == 9 && stage_ok(p, 64)) tile = 10;
         else if (tile == 4 && stage_ok(p, 32)) tile = 12;
         // plain NHWC reads in fp32 go through the LDS-DMA kernel (3-15 % faster per layer, same arithmetic order)
-        if (p.a_mode == A_NHWC && p.prec == 0 && default_dma()) {
+        if (p.a_mode == A_NHWC && p.prec == 0 && default_dma() && dma_range_ok(p)) {
             if (tile == 9 || tile == 10) tile = 20;
             else if (tile == 8 && stage_ok(p, 64)) tile = 22;
             else if (tile == 4 || tile == 12) tile = 23;
@@ -2386,6 +2396,7 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
                 tile = wgs128x128 >= 2304 ? 25 : ((p.cout >= 256 && p.cout % 128 == 0) ? 28 : 23);
         }
     }
+    if (tile >= 20 && tile <= 41 && !(p.a_mode == A_NHWC && dma_range_ok(p))) return hipErrorInvalidValue;   // explicit DMA tile, image too large
     if (tile_used) *tile_used = tile;
     g_last_launch.kernel = conv_tile_name(tile);
     if (p.prec != 0 && p.prec != 1 && p.prec != 3) return hipErrorInvalidValue;

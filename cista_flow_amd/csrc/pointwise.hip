@@ -369,8 +369,14 @@ hipError_t launch_inorm_stats(const float* x, int ld, long bs, int B, int HW, in
 // number of doubles launch_inorm_stats needs in `partial`
 long inorm_partial_doubles(int B, int HW, int C) { return (long)B * ((HW + IN_CHUNK - 1) / IN_CHUNK) * C * 2; }
 // ... and a convolution with fused statistics (ConvParams::st_partial, 32-pixel patches)
-// (x2: the Winograd kernel writes one partial per tile row of its 8 x 16 regions, up to ~1.3x as many on ragged sizes)
-long inorm_patch_doubles(int B, int HW, int C) { return (long)B * ((HW + 31) / 32) * C * 2 * 2 + 1024; }
+// per image max(32-pixel patches, 4 partials per Winograd region in either orientation of the 8 x 16 regions): on small ragged
+// maps the regions outnumber the patches (17 x 17: 24 partials against 10), so the bound is taken from (Ho, Wo), not from Ho*Wo
+long inorm_patch_doubles(int B, int Ho, int Wo, int C) {
+    const long patches = ((long)Ho * Wo + 31) / 32;
+    const long wide = 4L * ((Ho + 7) / 8) * ((Wo + 15) / 16), tall = 4L * ((Ho + 15) / 16) * ((Wo + 7) / 8);
+    const long chunks = patches > wide ? (patches > tall ? patches : tall) : (wide > tall ? wide : tall);
+    return (long)B * chunks * C * 2 + 1024;
+}
 
 __global__ __launch_bounds__(256) void inorm_apply_kernel(const float* __restrict__ x, int ld, long bs,
                                                           const float* __restrict__ stats, const float* __restrict__ res,

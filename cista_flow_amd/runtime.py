@@ -8,9 +8,11 @@ from . import lib as _lib
 # nn.Parameter / module goes through these hooks).  A backend re-collects its tensor list only when the epoch moved;
 # per frame it then compares (data_ptr, _version) of that cached list (~40 us for the 262 tensors of cista-eiflow
 # instead of ~360 us for a state_dict() walk): .to() / .cuda() change data_ptr, load_state_dict and in-place edits
-# bump _version.  Not seen: a plain tensor assigned over an existing BUFFER attribute (module.running_mean = t), which
-# nn.Module stores without calling a hook -- call module._backend.invalidate() (or load_state_dict) after that.
+# bump _version.  A plain tensor assigned over an existing BUFFER attribute (module.running_mean = t) or a direct edit of
+# module._parameters / _buffers goes through no hook: those are caught by the full re-collection every REWALK_EVERY frames
+# (a stale window of at most that many frames; amortised cost ~6 us per frame) -- or at once with backend.invalidate().
 _EPOCH = [0]
+REWALK_EVERY = 64
 
 
 def _bump(*_args, **_kw):
@@ -43,15 +45,20 @@ class HipBackend(object):
         self.handles = {}     # (B, device index) -> [Handle, weight signature]
         self._tensors = None  # cached state_dict tensors (see _EPOCH above)
         self._epoch = -1
+        self._age = 0         # frames since the tensor list was collected
 
     def _signature(self):
-        if not _HOOKS or self._tensors is None or self._epoch != _EPOCH[0]:
+        self._age += 1
+        if not _HOOKS or self._tensors is None or self._epoch != _EPOCH[0] or self._age >= REWALK_EVERY:
+            # a fresh list drops the references to tensors the module no longer holds
             self._tensors = list(self.module.state_dict(keep_vars=True).values())
             self._epoch = _EPOCH[0]
+            self._age = 0
         return tuple([(t.data_ptr(), t._version) for t in self._tensors])
 
     def invalidate(self):
-        """Force a re-pack of the weights on the next forward."""
+        """Force a re-pack of the weights on the next forward (after editing module._buffers / _parameters by hand or
+        assigning a plain tensor over a buffer attribute; everything else is detected automatically)."""
         self._tensors = None
         for ent in self.handles.values():
             ent[1] = None

@@ -252,6 +252,27 @@ def test_weights_follow_load_state_dict(gpu):
     assert torch.equal(I1, I3)
 
 
+def test_buffer_reassignment_is_picked_up(gpu):
+    """A plain tensor assigned over a BatchNorm buffer goes through no nn.Module hook: `invalidate()` re-packs at
+    once, and without it the periodic full re-collection (runtime.REWALK_EVERY frames) notices."""
+    from cista_flow_amd import runtime
+    H, W, B = 128, 128, 1
+    m = build_eiflow(H, W, 3, gpu)
+    ev = wu.synth_events(B, 5, H, W, 8).to(gpu)
+    prev = torch.zeros(B, 1, H, W, device=gpu)
+    bn = m.event_flownet.cnet.norm1
+    with torch.no_grad():
+        f1 = m({"event_voxel": ev, "rec_img0": prev}, None, {})[1]["flow_final"].clone()
+        bn.running_mean = bn.running_mean + 0.5          # new tensor object, no registration hook
+        m._be().invalidate()
+        f2 = m({"event_voxel": ev, "rec_img0": prev}, None, {})[1]["flow_final"].clone()
+        assert (f1 - f2).abs().max() > 1e-4
+        bn.running_mean = bn.running_mean - 0.5          # back, this time WITHOUT invalidate()
+        for _ in range(runtime.REWALK_EVERY + 1):
+            f3 = m({"event_voxel": ev, "rec_img0": prev}, None, {})[1]["flow_final"]
+        assert gu.rel_err(f3.cpu(), f1.cpu()) < 1e-6
+
+
 def test_inputs_are_validated(gpu):
     m = build_eiflow(128, 128, 3, gpu)
     with pytest.raises(ValueError):
