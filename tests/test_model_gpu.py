@@ -263,11 +263,12 @@ def test_buffer_reassignment_is_picked_up(gpu):
     bn = m.event_flownet.cnet.norm1
     with torch.no_grad():
         f1 = m({"event_voxel": ev, "rec_img0": prev}, None, {})[1]["flow_final"].clone()
+        orig = bn.running_mean.clone()
         bn.running_mean = bn.running_mean + 0.5          # new tensor object, no registration hook
         m._be().invalidate()
         f2 = m({"event_voxel": ev, "rec_img0": prev}, None, {})[1]["flow_final"].clone()
         assert (f1 - f2).abs().max() > 1e-4
-        bn.running_mean = bn.running_mean - 0.5          # back, this time WITHOUT invalidate()
+        bn.running_mean = orig                           # back, this time WITHOUT invalidate()
         for _ in range(runtime.REWALK_EVERY + 1):
             f3 = m({"event_voxel": ev, "rec_img0": prev}, None, {})[1]["flow_final"]
         assert gu.rel_err(f3.cpu(), f1.cpu()) < 1e-6
