@@ -41,6 +41,7 @@ struct RawWeight {
 struct PackedConv {
     float* w = nullptr;
     float* wino = nullptr;   // Winograd F(2x2,3x3) transform of w (3x3 convs, fp32 and f16x3 modes; conv_wino_kernel)
+    float* wino4 = nullptr;  // Winograd F(4x4,3x3) transform of w (3x3 convs, fp32 mode; conv_wino4_kernel)
     void* w16 = nullptr;     // f16 hi/lo split copy (precision != 0)
     float* bias = nullptr;
     int cout = 0, cin = 0, cin_pad = 0, KH = 0, KW = 0, Ktot = 0, rows = 0;
@@ -133,6 +134,7 @@ struct cf_handle {
     int last_tile = 0;             // tile kind of the last run_conv launch (statistics chunk count of the Winograd tile)
     bool enc_pair = false;         // CF_ENC_PAIR=1: fnet + enet as one 2B batch instead of two streams
     bool wino = true;              // CF_WINO=0: 3x3 convolutions on the direct implicit-GEMM kernel instead of Winograd F(2x2,3x3)
+    bool wino4 = true;             // CF_WINO4=0: no F(4x4,3x3) weights / kernel (conv_wino4_kernel)
     // CF_PHASES=1 (tuning aid): HIP events on the caller's stream at the phase boundaries of cf_step, averaged
     // and printed to stderr by cf_destroy
     bool phases = false;
@@ -241,14 +243,15 @@ static hipError_t run_conv(cf_handle* h, const ConvParams& p_in, int batch, hipS
         if (p.aux3) p.aux3 += b0 * p.aux3_bs;
         if (p.addend) p.addend += b0 * p.addend_bs;
     }
-    if (h && !h->wino) p.w_wino = nullptr;
+    if (h && !h->wino) { p.w_wino = nullptr; p.w_wino4 = nullptr; }
     if (h && h->enc_tile_batch > 0) p.tile_batch = h->enc_tile_batch;
     if (p.w_div < 0 && h && h->enc_group_sel >= 0) {      // one network of a grouped PackedConv on its own: fixed matrix
         p.w += (long)h->enc_group_sel * p.w_bs;
         if (p.w16) p.w16 = static_cast<const char*>(p.w16) + (long)h->enc_group_sel * p.w_bs * 4;
         if (p.bias) p.bias += (long)h->enc_group_sel * p.bias_gs;
         if (p.w_wino) p.w_wino += (long)h->enc_group_sel * p.wino_gs;
-        p.w_bs = 0; p.bias_gs = 0; p.w_div = 0; p.wino_gs = 0;
+        if (p.w_wino4) p.w_wino4 += (long)h->enc_group_sel * p.wino4_gs;
+        p.w_bs = 0; p.bias_gs = 0; p.w_div = 0; p.wino_gs = 0; p.wino4_gs = 0;
     }
     if (p.w_div < 0) {
         if (batch % (-p.w_div) != 0) return hipErrorInvalidValue;
@@ -468,11 +471,13 @@ ConvParams nhwc_conv(const PackedConv& pc, std::initializer_list<Seg> segs, int 
     p.a_mode = A_NHWC;
     p.w = pc.w; p.w16 = pc.w16; p.w_bs = 0; p.w_rows = pc.rows; p.Ktot = pc.Ktot; p.cin_pad = pc.cin_pad; p.bias = pc.bias;
     p.w_wino = pc.wino;
+    p.w_wino4 = pc.wino4;
     if (pc.groups > 1) {     // images [g*batch/groups, (g+1)*batch/groups) use matrix g; run_conv turns w_div into images per group
         p.w_bs = (long)pc.rows * pc.Ktot;
         p.bias_gs = pc.rows;
         p.w_div = -pc.groups;
         p.wino_gs = pc.wino ? wino_weight_floats(pc.cout, pc.cin_pad) : 0;
+        p.wino4_gs = pc.wino4 ? wino4_weight_floats(pc.cout, pc.cin_pad) : 0;
     }
     p.out = out; p.out_ld = out_ld; p.out_bs = out_bs; p.cout = pc.cout; p.epi = epi;
     p.k_real = pc.cin * pc.KH * pc.KW;
@@ -778,6 +783,13 @@ extern "C" int cf_finalize_weights(cf_handle* h, void* stream) {
             h->owned.push_back(pc.wino);
             for (int g = 0; g < pc.groups; ++g)
                 CF_HIP(h, launch_wino_weights(pc.w + (size_t)g * pc.rows * pc.Ktot, pc.wino + g * wf, pc.cout, pc.cin_pad, st));
+            if (h->cfg.precision == 0 && h->wino4) {      // F(4x4,3x3): four times the packed matrix
+                const size_t wf4 = (size_t)wino4_weight_floats(pc.cout, pc.cin_pad);
+                CF_HIP(h, hipMalloc(reinterpret_cast<void**>(&pc.wino4), sizeof(float) * wf4 * pc.groups));
+                h->owned.push_back(pc.wino4);
+                for (int g = 0; g < pc.groups; ++g)
+                    CF_HIP(h, launch_wino4_weights(pc.w + (size_t)g * pc.rows * pc.Ktot, pc.wino4 + g * wf4, pc.cout, pc.cin_pad, st));
+            }
         }
     }
     if (h->cfg.precision != 0) {
@@ -840,6 +852,7 @@ extern "C" int cf_create(cf_handle** out, const cf_config* cfg) {
     }
     if (const char* e = getenv("CF_ENC_PAIR")) h->enc_pair = atoi(e) != 0;      // before the arena is laid out
     if (const char* e = getenv("CF_WINO")) h->wino = atoi(e) != 0;
+    if (const char* e = getenv("CF_WINO4")) h->wino4 = atoi(e) != 0;
     if (const char* e = getenv("CF_ARENA_SKEW")) h->arena.skew = (size_t)atol(e) & ~size_t(255);
     if (const char* e = getenv("CF_ARENA_ALIGN")) {
         const size_t a = (size_t)atol(e);
@@ -1907,6 +1920,12 @@ static int op_conv2d_impl(const float* in, int B, int Cin, int H, int W, const f
         if (launch_split_weight_f16(pc.w, w16.p, pc.rows, pc.Ktot, st) != hipSuccess) return CF_ERR_HIP;
         p.w16 = w16.p;
         p.prec = prec;
+    }
+    TmpBuf wino4;
+    if (tile == 42 && !gather && KH == 3 && KW == 3) {
+        if (hipMalloc(&wino4.p, sizeof(float) * (size_t)wino4_weight_floats(Cout, pc.cin_pad)) != hipSuccess) return CF_ERR_HIP;
+        if (launch_wino4_weights(pc.w, static_cast<float*>(wino4.p), Cout, pc.cin_pad, st) != hipSuccess) return CF_ERR_HIP;
+        p.w_wino4 = static_cast<float*>(wino4.p);
     }
     TmpBuf wino;
     if ((tile == 40 || tile == 41) && !gather && KH == 3 && KW == 3) {      // Winograd tile: needs the transformed weights

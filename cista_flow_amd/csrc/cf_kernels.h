@@ -76,6 +76,8 @@ struct ConvParams {
     const float* w;
     const float* w_wino; // Winograd F(2x2,3x3) transform of w (launch_wino_weights; nullable): enables tile 40
     long wino_gs;       // floats between the Winograd matrices of consecutive weight groups (w_div)
+    const float* w_wino4; // Winograd F(4x4,3x3) transform of w (launch_wino4_weights; nullable): enables tile 42
+    long wino4_gs;
     const void* w16;    // f16 split copy of w (nullable; f16 modes fall back to splitting B while staging)
     long w_bs;          // weight stride between image groups (0 for ordinary weights; N*D for the correlation GEMM)
     int  w_div;         // images per weight group (<= 1: one matrix per image when w_bs != 0).  Two networks with the
@@ -118,6 +120,13 @@ const char* conv_tile_name(int tile);
 // U = G g G^T of a packed 3x3 matrix [rows][9][cin_pad] in conv_wino_kernel's block layout (wino_weight_floats floats)
 hipError_t launch_wino_weights(const float* w, float* u, int rows, int cin_pad, hipStream_t s);
 long wino_weight_floats(int rows, int cin_pad);
+// the same for F(4x4,3x3) (conv_wino4_kernel's [n-block][chunk][36 pos][32 n][8 k] layout)
+hipError_t launch_wino4_weights(const float* w, float* u, int rows, int cin_pad, hipStream_t s);
+long wino4_weight_floats(int rows, int cin_pad);
+// conv_wino4.hip, reached through launch_conv (tile 42)
+bool wino4_ok(const ConvParams& p);
+int wino4_regions(int Ho, int Wo);
+hipError_t launch_wino4(const ConvParams& p, int batch, hipStream_t s);
 // number of statistics partials per image a convolution with st_partial writes (tile = the tile launch_conv used)
 int conv_stats_chunks(const ConvParams& p, int tile);
 // f16 split copy of a packed weight matrix (same byte size, LDS chunk format [16 hi | 16 lo])

@@ -141,6 +141,10 @@ STATS_CASES = [
     (64, 64, 3, 3, 1, 1, 0, 40, 48, 64),     # Winograd tile: one partial per tile row of an 8 x 16 region
     (96, 96, 3, 3, 1, 1, 0, 40, 21, 37),     # ... ragged regions
     (64, 128, 3, 3, 1, 1, 0, 41, 21, 37),    # eight-wave Winograd tile
+    (64, 64, 3, 3, 1, 1, 0, 42, 48, 64),     # F(4x4,3x3): sixteen partials per 32-tile region
+    (96, 96, 3, 3, 1, 1, 0, 42, 21, 37),     # ... ragged regions
+    (64, 160, 3, 3, 1, 1, 0, 42, 17, 17),    # ... a small ragged map with B * Cout > 128 (partial-buffer sizing)
+    (64, 160, 3, 3, 1, 1, 0, 40, 17, 17),
 ]
 
 
@@ -218,6 +222,33 @@ def test_conv_winograd(gpu, case):
         got8 = run_conv(gpu, x, w, b, 1, 1, 1, pad_mode, 0, epi, 41, H, W)
         assert (got8 - ref).abs().max().item() < 1e-4
         assert (got8 - direct).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+WINO4_CASES = WINO_CASES + [(64, 64, 1, 96, 128, 1), (128, 64, 1, 37, 50, 0), (16, 40, 0, 12, 12, 0), (80, 32, 1, 16, 32, 0),
+                            (64, 128, 0, 45, 16, 0), (64, 128, 0, 16, 45, 0)]
+
+
+@pytest.mark.parametrize("case", WINO4_CASES)
+def test_conv_winograd_f4x4(gpu, case):
+    """conv_wino4_kernel (tile 42): Winograd F(4x4,3x3), both region orientations (16 x 32 and 32 x 16 output pixels), ragged
+    regions, reflect and zero padding, partial output-channel blocks, channel counts that are multiples of 8 only, fused
+    activations -- against F.conv2d (fp32) and against the direct kernel.  F(4x4,3x3)'s transforms round more than F(2x2,3x3)'s
+    (interpolation points +-2: coefficients up to 8 and 1/24): 1e-5 of the tensor scale per layer is what it costs, 4e-5 asserted."""
+    Cin, Cout, pad_mode, H, W, epi = case
+    g = torch.Generator().manual_seed(2000 + Cin + Cout + H)
+    B = 2
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref64 = ref_conv(x.double(), w.double(), b.double(), 1, 1, 1, pad_mode)
+    act = {0: lambda t: t, 1: torch.relu, 2: torch.sigmoid, 3: torch.tanh}[epi]
+    scale = max(1.0, ref64.abs().max().item())
+    ref = act(ref64).float()
+    got = run_conv(gpu, x, w, b, 1, 1, 1, pad_mode, 0, epi, 42, H, W)
+    assert got.shape == ref.shape
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() < 4e-5 * scale, (got - ref).abs().max().item()
+    assert torch.equal(got, run_conv(gpu, x, w, b, 1, 1, 1, pad_mode, 0, epi, 42, H, W))     # deterministic
 
 
 @pytest.mark.parametrize("epi", [1, 2, 3])

@@ -163,12 +163,14 @@ def test_event_preprocess_on_device_and_cropped_grids(gpu):
     raw_ref = orc.events_to_voxel(txyp, 5, 346, 260, False, False)
     dev_ev = [torch.as_tensor(txyp).to(gpu)]
     raw = events_to_voxel_grid_batch(dev_ev, 5, 346, 260, normalize=False)
-    assert np.abs(raw[0].cpu().numpy() - raw_ref).max() < 1e-5
+    # float atomics vs np.add.at: the hot pixel sums several hundred contributions, so compare relative to the grid's scale
+    scale = max(1.0, float(np.abs(raw_ref).max()))
+    assert np.abs(raw[0].cpu().numpy() - raw_ref).max() < 5e-6 * scale
     # hot filter alone
     hot = events_to_voxel_grid_batch(dev_ev, 5, 346, 260, normalize=False, filter_hot_pixel=True)[0].cpu().numpy()
     ref_hot = raw_ref.copy()
     ref_hot[np.abs(ref_hot) > 25.0 / 5] = 0
-    assert np.abs(raw_ref).max() > 5.0 and np.abs(hot).max() <= 5.0 and np.abs(hot - ref_hot).max() < 1e-5
+    assert np.abs(raw_ref).max() > 5.0 and np.abs(hot).max() <= 5.0 and np.abs(hot - ref_hot).max() < 2e-5
     # crop, then filter + normalise (two grids in one call; each grid on its own statistics)
     crop = raw[:, :, 2:258, 45:301].contiguous()
     both = torch.cat([crop, 0.5 * crop], 0)
