@@ -558,4 +558,20 @@ static inline bool dma_range_ok(const ConvParams& p) {
     return true;
 }
 
+
+#ifdef CF_CENSUS
+// residency census (tools/census_probe.py): wave 0 of every workgroup records where and when it ran --
+// [HW_ID, XCC_ID, start, end] (100 MHz real-time counter) -- so that the number of workgroups a CU really holds at once can be counted
+__device__ __forceinline__ void census_begin(const ConvParams& p, long long& t0) { t0 = (long long)__builtin_amdgcn_s_memrealtime(); }
+__device__ __forceinline__ void census_end(const ConvParams& p, long long t0) {
+    if (p.stamp && threadIdx.x == 0) {
+        long long* q = p.stamp + (long)blockIdx.x * 4;
+        q[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_REG_HW_ID
+        q[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);       // HW_REG_XCC_ID
+        q[2] = t0;
+        q[3] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
+}
+#endif
+
 }  // namespace cf

@@ -916,6 +916,10 @@ static constexpr int WG_UV = 16 * 32 * WG_KC;               // floats of a chunk
 #define WG_ABL 0
 #endif
 __global__ __launch_bounds__(256, 4) void conv_wino_kernel(const ConvParams p) {
+#ifdef CF_CENSUS
+    long long c0;
+    census_begin(p, c0);
+#endif
 #ifdef CF_STAMP
     const long long t_begin = __builtin_readcyclecounter();
     const long long r_begin = (long long)__builtin_amdgcn_s_memrealtime();
@@ -934,10 +938,16 @@ __global__ __launch_bounds__(256, 4) void conv_wino_kernel(const ConvParams p) {
     // weights, so each lane fetches its own B fragments (16 bytes, L2 hits) straight into registers.
     constexpr int WG_A = 4 * 2 * 32 * 32;
     static_assert(2 * WG_RAW <= WG_A && 4 * 32 * EPI_S <= WG_A, "raw ring and epilogue patches overlay the exchange buffer");
+#ifdef CF_LDS32K
+    static_assert(4 * 32 * EPI_S + 4 * 32 <= WG_A, "the row -> pixel tables sit behind the epilogue patches, inside the dead exchange buffer");
+    __shared__ __attribute__((aligned(16))) float smem[WG_A];            // 32,768 bytes exactly
+    int* const sMtab = reinterpret_cast<int*>(smem + 4 * 32 * EPI_S);
+#else
     __shared__ __attribute__((aligned(16))) float smem[WG_A + 4 * 32];
+    int* const sMtab = reinterpret_cast<int*>(smem + WG_A);
+#endif
     float* const sRaw = smem;
     float* const sPatch = smem;
-    int* const sMtab = reinterpret_cast<int*>(smem + WG_A);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1157,6 +1167,9 @@ __global__ __launch_bounds__(256, 4) void conv_wino_kernel(const ConvParams p) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     patch_tail(p, sW, b, 0, n0, lane, Ho * Wo, 0, 4, 1, 0, mtab);
     if (p.st_partial) patch_stats(p, sW, b, 0, n0, lane, Ho * Wo, mtab, reg * 4 + wave, nreg * 4);
+#ifdef CF_CENSUS
+    census_end(p, c0);
+#endif
 #ifdef CF_STAMP
     if (p.stamp && lane == 0) {      // [DMA wait + barrier, second barrier, issue + transform, prologue, chunks, loop, tail, MHz]
         long long* q = p.stamp + ((long)blockIdx.x * 4 + wave) * 8;
@@ -1732,7 +1745,7 @@ static int default_dma() {
 
 hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int tile, int* tile_used) {
     ConvParams p = p_in;
-#ifdef CF_STAMP
+#if defined(CF_STAMP) || defined(CF_CENSUS)
     { const char* e = getenv("CF_STAMP_BUF"); p.stamp = e ? reinterpret_cast<long long*>(strtoull(e, nullptr, 10)) : nullptr; }
 #endif
     if (p.sched < 0) p.sched = default_sched();

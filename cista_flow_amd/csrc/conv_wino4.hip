@@ -12,45 +12,48 @@ namespace cf {
 // network on the CPU oracle against the reference goldens BEFORE this kernel was written: worst 2.1e-5 with EVERY
 // 3x3 / stride-1 layer replaced; the regression bar of the tests is 2e-4, the contract 1e-3).
 //
-// One workgroup = 6 waves (384 threads) = a region of 32 tiles (4 x 8 tiles = 16 x 32 output pixels "wide", or 8 x 4 =
-// 32 x 16 "tall") x 32 output channels; K = Cin in chunks of 8 channels:
-//   raw    the (18 x 34 or 34 x 18 pixel) x 8-channel input patch of a chunk, LDS-DMA'd from the NHWC tensor (reflect / zero
-//          padding resolved in the per-lane source offset once per workgroup), double buffered; two channel-quad planes of
-//          16-byte slots, the columns of a patch row stored by residue class (px mod 4) so that the tiles of a tile row read
-//          neighbouring slots and the 16 lanes of a ds_read_b128 group hit 16 different bank quads;
-//   MFMA   wave i owns positions (i, 0..5) = row i of B^T d B: 6 accumulators [32 tiles x 32 couts] = 96 registers, 24 x
-//          v_mfma_f32_32x32x2_f32 per chunk;
+// One workgroup = 6 waves (384 threads) = a region of 4 x 8 tiles (16 x 32 output pixels) x 32 output channels; K = Cin in
+// chunks of 16 channels:
+//   raw    the (18 x 34 pixel) x 16-channel input patch of a chunk, LDS-DMA'd from the NHWC tensor (reflect / zero padding
+//          resolved in the per-lane source offset once per workgroup), double buffered.  FOUR consecutive lanes of a DMA
+//          instruction fetch the four channel quads of one patch cell = 64 contiguous bytes: an instruction touches 16 cache
+//          lines instead of 64 (the first version fetched 16 bytes per lane from 64 different lines and was bound by the
+//          texture-address / L1-fill path at 0.35 of the matrix peak, with 4x more bytes moved from L2 than used).  Cell
+//          (py, px) lives at 16-byte slot 4 c + (f ^ quad), c = 34 py + perm(px) (columns stored by residue class px mod 4, so
+//          the tiles of a tile row read neighbouring cells), f = 2 bits of the cell's position: the 16 lanes of a ds_read_b64
+//          group then hit 16 different bank granules;
+//   MFMA   wave i owns positions (i, 0..5) = row i of B^T d B: 6 accumulators [32 tiles x 32 couts] = 96 registers, 48 x
+//          v_mfma_f32_32x32x2_f32 per chunk in four steps of 12 (one channel pair of each lane's quad per step);
 //   V      never stored.  Row i of B^T d is a 4-term combination of patch rows (coefficients and rows are wave-uniform
-//          scalars: 4 d0 - 5 d2 + d4 | d4 - 4 d2 +- (d3 - 4 d1) | d4 - d2 +- 2 (d3 - d1) | 4 d1 - 5 d3 + d5): lane (tile, channel
-//          quad) reads 4 rows x 6 pixels (ds_read_b128 straight from the raw patch), then applies the row transform along
-//          the 6 columns in registers, a channel PAIR at a time (the A operands of 12 MFMAs) to stay inside 168 registers
-//          (three waves per SIMD = two workgroups per CU);
-//   U      = G g G^T (fp64 at weight-pack time, rounded once), [n-block][chunk][36 pos][32 n][8 k]; every lane loads its own
-//          B fragments (8 bytes per position and channel pair) from L2 half a chunk ahead, behind that position's MFMAs;
-//   tail   A^T . A is separable: along j in registers (6 -> 4), along i across the six waves through LDS one output
-//          column j' at a time (X[6][32 tiles][32 couts] = 24 KB over the raw ring); waves 0..3 each finish output row
-//          i' of every tile as a 32-row patch through the common fused epilogue (patch_tail with a row -> pixel table).
+//          scalars: 4 d0 - 5 d2 + d4 | d4 - 4 d2 +- (d3 - 4 d1) | d4 - d2 +- 2 (d3 - d1) | 4 d1 - 5 d3 + d5): lane (tile, pair)
+//          reads 4 rows x 6 pixels (ds_read_b64 straight from the raw patch), then applies the row transform along the 6
+//          columns in registers.  Software pipeline: the A operands of step s + 1 are built in the shadow of the 12 MFMAs of
+//          step s (column j right behind position j's MFMAs), inside 168 registers = three waves per SIMD = two workgroups per CU;
+//   U      = G g G^T (fp64 at weight-pack time, rounded once), [n-block][chunk][36 pos][4 steps][32 n][2][2]: the 64 lanes of
+//          a load read 512 contiguous bytes; every lane loads its own B fragments one step ahead, behind that position's MFMAs;
+//   tail   A^T . A is separable: along j in registers (6 -> 4), along i across the six waves through LDS (two output
+//          columns j' per round); waves 0..3 each finish output row i' of every tile as four 32-row patches through the
+//          common fused epilogue (patch_tail with a row -> pixel table) once the accumulators are dead.
 // ---------------------------------------------------------------------------------------------------------
-static constexpr int W4_SLOTS = 1536;                        // 16-byte slots per raw buffer: 24 wave-instructions of LDS-DMA
-static constexpr int W4_PLANE = 768;                         // slots per channel-quad plane (612 / 646 live)
-static constexpr int W4_RAW = W4_SLOTS * 4;                  // floats per raw buffer
-static constexpr int W4_UV = 36 * 32 * 8;                    // floats of a chunk's U block (9216)
+static constexpr int W4_KC = 16;                             // channels per chunk
+static constexpr int W4_CELLS = 18 * 34;                     // patch cells (612)
+static constexpr int W4_NDMA = (W4_CELLS * 4 + 63) / 64;     // wave-instructions of LDS-DMA per chunk (39; the last one has 48 dead slots)
+static constexpr int W4_RAW = W4_NDMA * 64 * 4;              // floats per raw buffer (39,936 bytes)
+static constexpr int W4_UV = 36 * 4 * 32 * 4;                // floats of a chunk's U block (18432)
 static constexpr int W4_X = 6 * 2 * 32 * 32;                 // floats of the cross-wave exchange buffer of the tail (48 KB)
-static constexpr int W4_SMEM = W4_X + 4 * 32 * EPI_S + 4 * 32;   // + four epilogue patches + their row -> pixel tables (66.5 KB: two workgroups per CU)
-static_assert(2 * W4_RAW <= W4_SMEM, "the raw ring lies under the tail's buffers");
-__host__ __device__ inline int wino4_tall(int Ho, int Wo) {
-    const long wide = (long)((Ho + 15) / 16 * 16) * ((Wo + 31) / 32 * 32), tall = (long)((Ho + 31) / 32 * 32) * ((Wo + 15) / 16 * 16);
-    return tall < wide ? 1 : 0;
-}
+static constexpr int W4_TAIL = W4_X + 4 * 32 * EPI_S + 4 * 32;   // + four epilogue patches + their row -> pixel tables (floats)
+static constexpr int W4_SMEM = 4 * (2 * W4_RAW > W4_TAIL ? 2 * W4_RAW : W4_TAIL);   // bytes: 79,872 -> two workgroups per CU (159,744 of 163,840)
 
-template <int TALL>
 __device__ __forceinline__ void wino4_body(const ConvParams& p, float* smem) {
-    constexpr int TWr = TALL ? 4 : 8, THr = 32 / TWr;        // tile columns / rows of a region
-    constexpr int RH = 4 * THr, RW = 4 * TWr;                // region size in output pixels
-    constexpr int PR = RH + 2, PC = RW + 2;                  // patch rows / columns
-    constexpr int P = TALL ? 19 : 34;                        // slots per patch row: 4 P mod 16 in {8, 12} keeps tile rows off each other's banks
-    constexpr int OFF1 = (PC + 3) / 4, OFF2 = OFF1 + (PC + 2) / 4, OFF3 = OFF2 + (PC + 1) / 4;   // first slot of column class px mod 4 = 1, 2, 3
-    static_assert(PR * P <= W4_PLANE, "plane");
+#ifdef CF_STAMP
+    const long long t_begin = __builtin_readcyclecounter();
+    const long long r_begin = (long long)__builtin_amdgcn_s_memrealtime();
+    long long st_wait = 0, st_dma = 0, st_s012 = 0;
+#endif
+    constexpr int TWr = 8;                                   // tile columns of a region (4 tile rows)
+    constexpr int RH = 16, RW = 32;                          // region size in output pixels
+    constexpr int PC = 34;                                   // patch columns (18 rows)
+    constexpr int OFF1 = 9, OFF2 = 18, OFF3 = 26;            // first cell of column class px mod 4 = 1, 2, 3 within a patch row (9 + 9 + 8 + 8 columns)
     float* const sRaw = smem;
 
     const int tid = threadIdx.x;
@@ -74,45 +77,55 @@ __device__ __forceinline__ void wino4_body(const ConvParams& p, float* smem) {
     const int oy0 = (reg / nrx) * RH, ox0 = (reg % nrx) * RW;
     const int n0 = nblk * 32;
 
-    // ---- raw patch DMA slots: wave-instruction id = 6 j + wave covers slots [64 id, 64 id + 64) of a buffer ----
-    int a_pix[4];
-    unsigned a_q[4];
+    // ---- raw patch DMA: wave-instruction id = wave + 6 j covers slots [64 id, 64 id + 64) of a buffer; slot -> (cell, quad).
+    // Per slot a 16-bit descriptor (two per register: the loop has no registers to spare): source pixel relative to the patch origin
+    // after padding resolution -- row 0..63 | column 0..127 << 6 | quad << 13 | dead << 15 ----
+    unsigned a_src[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int sl = 64 * (6 * j + wave) + lane;
-        const int plane = sl / W4_PLANE, cs = sl - plane * W4_PLANE;
-        const int py = cs / P, pcs = cs - py * P;
-        const int r = pcs >= OFF3 ? 3 : pcs >= OFF2 ? 2 : pcs >= OFF1 ? 1 : 0;
-        const int px = 4 * (pcs - (r == 3 ? OFF3 : r == 2 ? OFF2 : r == 1 ? OFF1 : 0)) + r;
-        a_q[j] = (unsigned)(plane & 1) * 16u;
+    for (int j = 0; j < 7; ++j) {
+        const int sl = 64 * (wave + 6 * j) + lane;
+        const int c = sl >> 2;
+        const int py = c / PC, u = c - py * PC;
+        const int r = u >= OFF3 ? 3 : u >= OFF2 ? 2 : u >= OFF1 ? 1 : 0;
+        const int px = 4 * (u - (r == 3 ? OFF3 : r == 2 ? OFF2 : r == 1 ? OFF1 : 0)) + r;
+        const int f = ((u >> 2) & 1) | (((py >> 2) & 1) << 1);
+        const int quad = (sl & 3) ^ f;
         int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
-        bool ok = plane < 2 && py < PR && pcs < PC && iy <= p.Hin && ix <= p.Win;   // beyond the halo of the last row / column: unused
+        bool ok = c < W4_CELLS && iy <= p.Hin && ix <= p.Win;       // beyond the halo of the last row / column: unused
         if (p.pad_mode == 1) {
             iy = reflect_idx(iy, p.Hin);
             ix = reflect_idx(ix, p.Win);
         } else {
             ok = ok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
         }
-        a_pix[j] = ok ? iy * p.Win + ix : -1;
+        // reflection moves a coordinate by at most 2 around the patch: (iy - oy0 + 8) in 0..63, (ix - ox0 + 8) in 0..127
+        const unsigned d = ok ? (unsigned)(iy - oy0 + 8) | ((unsigned)(ix - ox0 + 8) << 6) | ((unsigned)quad << 13) : 0x8000u;
+        a_src[j >> 1] |= d << (16 * (j & 1));
     }
-    const int nchunk = p.cin_pad / 8;
+    const int pix0 = (oy0 - 8) * p.Win + (ox0 - 8);               // pixel index of descriptor (0, 0)
+    const int nchunk = p.cin_pad / W4_KC;
     const __amdgpu_buffer_rsrc_t u_rsrc = make_rsrc(p.w_wino4 + (long)wgroup(p, b) * p.wino4_gs + (long)nblk * nchunk * W4_UV);
 
     int it_seg = 0, it_cs = 0;
     const float* seg_base = p.in[0] + (long)b * p.seg_bs[0];
     int seg_ld = p.seg_ld[0], seg_cn = p.seg_c[0];
-    // every wave issues exactly four DMA instructions per chunk, unconditionally (dead slots and the chunk past the end fetch
-    // out of range = zeros): fixed counts keep the compiler's vmcnt waits in front of the MFMAs on the U registers alone
+    // dead slots and the chunks past the end fetch out of range (= zeros into LDS): the issue pattern never changes
     auto issue_raw = [&](int buf, bool live) __attribute__((always_inline)) {
         const __amdgpu_buffer_rsrc_t rs = make_rsrc(seg_base);
         const unsigned ld4 = (unsigned)seg_ld * 4u, so = (unsigned)it_cs * 4u;
         float* rbase = sRaw + buf * W4_RAW;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned off = (a_pix[j] < 0 || !live) ? BUF_OOB : (unsigned)a_pix[j] * ld4 + a_q[j];
-            dma16_to_lds(rs, rbase + 64 * (6 * j + wave) * 4, off, so);
+        for (int j = 0; j < 7; ++j) {
+            if (wave + 6 * j < W4_NDMA) {           // wave-uniform: the seventh piece exists for waves 0..2 only
+                unsigned w = a_src[j >> 1];
+                asm volatile("" : "+v"(w));         // decode HERE, per chunk: hoisted out of the loop the seven decoded offsets would spill
+                const unsigned d = (w >> (16 * (j & 1))) & 0xFFFFu;
+                const int pix = pix0 + (int)(d & 63u) * p.Win + (int)((d >> 6) & 127u);
+                const unsigned off = ((d & 0x8000u) || !live) ? BUF_OOB : (unsigned)pix * ld4 + ((d >> 13) & 3u) * 16u;
+                dma16_to_lds(rs, rbase + 64 * (wave + 6 * j) * 4, off, so);
+            }
         }
-        it_cs += 8;
+        it_cs += W4_KC;
         if (it_cs >= seg_cn) {
             it_cs = 0;
             ++it_seg;
@@ -130,8 +143,9 @@ __device__ __forceinline__ void wino4_body(const ConvParams& p, float* smem) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-    // lane (lr, lh): tile lr = (tty, ttx) of the region, channel quad lh.  Row `wave` of B^T d = k0 d[ra] + k1 d[rb] + k2 d[rc] + k3 d[rd]
-    // (waves 0 and 5 have three terms: their last row is taken twice at half weight -- exact -- instead of a zero coefficient)
+    // lane (lr, lh): tile lr = (tty, ttx) of the region, channel pair lh of the step's quad.  Row `wave` of B^T d =
+    // k0 d[ra] + k1 d[rb] + k2 d[rc] + k3 d[rd] (waves 0 and 5 have three terms: their last row is taken twice at half weight --
+    // exact -- instead of a zero coefficient)
     const int lr = lane & 31, lh = lane >> 5;
     const int tty = lr / TWr, ttx = lr - tty * TWr;
     const bool edge = wave == 0 || wave == 5;
@@ -140,74 +154,138 @@ __device__ __forceinline__ void wino4_body(const ConvParams& p, float* smem) {
     const float k1 = edge ? -5.f : (wave == 1 || wave == 2) ? -4.f : -1.f;
     const float k2 = edge ? .5f : wave == 1 ? 1.f : wave == 2 ? -1.f : wave == 3 ? 2.f : -2.f;
     const float k3 = edge ? .5f : 1.f;
-    const int rd0 = (lh * W4_PLANE + 4 * tty * P + ttx) * 4;                      // floats; + row * P * 4 + column slot * 4
-    const int oa = rd0 + ra * P * 4, ob = rd0 + rb * P * 4, oc = rd0 + rc * P * 4, od = rd0 + rd * P * 4;
-    // U: position (wave, j), output channel lr, channels 4 lh + 2 q + {0, 1} of the chunk
-    const unsigned uoff = (unsigned)(lr * 8 + 4 * lh) * 4u;                         // lane part; the wave-uniform part goes in the scalar offset
-    const unsigned ubase = (unsigned)(wave * 6) * 1024u;
+    auto sgpr = [](float x) __attribute__((always_inline)) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); };
+    const float k0s = sgpr(k0), k1s = sgpr(k1), k2s = sgpr(k2), k3s = sgpr(k3);      // scalar operands of the column FMAs
+    // byte address of (row a, column bq, quad t) in a raw buffer: 64 c + 16 (f ^ t) + 8 lh with c = 34 (4 tty + a) + perm(bq) + ttx,
+    // f = bit 2 of (perm(bq) + ttx) | ((tty + (a >= 4)) & 1) << 1.  perm(bq) mod 8 is 0, 1 or 2, so three lane bases cover the six
+    // columns; rows >= 4 and the quad enter as an XOR on bits 4..5, the row / column displacement as a scalar + immediate offset
+    int abase[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+        abase[m] = 64 * (34 * 4 * tty + ttx) + 16 * ((((m + ttx) >> 2) & 1) | ((tty & 1) << 1)) + 8 * lh;
+    const int ro_a = 64 * 34 * ra, ro_b = 64 * 34 * rb, ro_c = 64 * 34 * rc, ro_d = 64 * 34 * rd;    // wave-uniform row displacements (bytes)
+    const int xr_c = rc >= 4 ? 32 : 0;                                                               // rows 4, 5 flip the row bit (rd always does)
+    // U: [pos][step][n][lh][2]: lane part n * 16 + lh * 8 bytes; the rest is wave-uniform
+    const unsigned uoff = (unsigned)(lr * 16 + lh * 8);
+    const unsigned ubase = (unsigned)(wave * 6) * 2048u;
 
     f32x2 bu[6];
-    const f32x2 k0v = {k0, k0}, k1v = {k1, k1}, k2v = {k2, k2}, k3v = {k3, k3};
-    auto chunk_step = [&](int k) __attribute__((always_inline)) {
-        // everything this wave has in flight -- the four raw(k) pieces, then the six U(k, first pair) loads, which the first MFMAs
-        // need anyway -- has landed before the hand-off
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        raw_barrier();                              // raw(k) has landed for everybody; everybody has read raw(k-1)
-        const bool more = k + 1 < nchunk;
-        issue_raw((k + 1) & 1, more);
+    struct Col { f32x2 a, b, c, d; };
+    // column bq of the patch for quad t (compile-time) out of the raw buffer at byte offset `bo` (wave-uniform)
+    auto read_col = [&](int bo, int bq, int t) __attribute__((always_inline)) {
+        constexpr int PERM[6] = {0, OFF1, OFF2, OFF3, 1, OFF1 + 1};
+        const int m = PERM[bq] & 7;                                   // 0, 1, 2, 2, 1, 2
+        int base = abase[m];
+        asm volatile("" : "+v"(base));              // keep the XOR / add per read: hoisted, the 36 loop-invariant addresses would spill
+        const char* r = reinterpret_cast<const char*>(sRaw);
+        const int disp = bo + 64 * PERM[bq];
+        Col x;
+        x.a = *reinterpret_cast<const f32x2*>(r + ((base ^ (16 * t)) + (ro_a + disp)));
+        x.b = *reinterpret_cast<const f32x2*>(r + ((base ^ (16 * t)) + (ro_b + disp)));
+        x.c = *reinterpret_cast<const f32x2*>(r + ((base ^ ((16 * t) ^ xr_c)) + (ro_c + disp)));
+        x.d = *reinterpret_cast<const f32x2*>(r + ((base ^ ((16 * t) ^ 32)) + (ro_d + disp)));
+        return x;
+    };
+    // scalar FMAs on purpose: the coefficients are wave-uniform and ride in SGPR operands (the packed forms want them in VGPR pairs,
+    // six registers this kernel does not have)
+    auto col_xf = [&](const Col& x) __attribute__((always_inline)) {
+        f32x2 c;
+        c[0] = __builtin_fmaf(k0s, x.a[0], __builtin_fmaf(k1s, x.b[0], __builtin_fmaf(k2s, x.c[0], k3s * x.d[0])));
+        c[1] = __builtin_fmaf(k0s, x.a[1], __builtin_fmaf(k1s, x.b[1], __builtin_fmaf(k2s, x.c[1], k3s * x.d[1])));
+        return c;
+    };
+    auto row_xf = [&](const f32x2 (&c)[6], f32x2 (&v)[6]) __attribute__((always_inline)) {
+        const f32x2 m4 = {-4.f, -4.f}, m5 = {-5.f, -5.f}, p4 = {4.f, 4.f}, p2 = {2.f, 2.f}, m2 = {-2.f, -2.f};
+        const f32x2 t1 = __builtin_elementwise_fma(m4, c[2], c[4]), t2 = __builtin_elementwise_fma(m4, c[1], c[3]);
+        const f32x2 t3 = c[4] - c[2], t4 = c[3] - c[1];
+        v[0] = __builtin_elementwise_fma(p4, c[0], __builtin_elementwise_fma(m5, c[2], c[4]));
+        v[5] = __builtin_elementwise_fma(p4, c[1], __builtin_elementwise_fma(m5, c[3], c[5]));
+        v[1] = t1 + t2;
+        v[2] = t1 - t2;
+        v[3] = __builtin_elementwise_fma(p2, t4, t3);
+        v[4] = __builtin_elementwise_fma(m2, t4, t3);
+    };
+    // one step: the 12 MFMAs on (v, bu) with the transform of the NEXT step (raw buffer at byte offset bo, quad tn) in their shadow;
+    // u_off = scalar byte offset of the U block that refills bu (the next step's)
+    auto step = [&](f32x2 (&v)[6], int bo, int tn, unsigned u_off) __attribute__((always_inline)) {
+        f32x2 cn[6];
+        Col xa = read_col(bo, 0, tn), xb;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            // the empty asm statements pin WHERE the packed-math results exist: without them instruction selection places the whole
+            // transform behind the last MFMA (pure arithmetic carries no chain), and the wave is back to two serial phases
+            asm volatile("" : "+v"(v[j]));
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][0], bu[j][0], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][1], bu[j][1], acc[j], 0, 0, 0);
+            bu[j] = buf_load2(u_rsrc, uoff, u_off + 2048u * j);
+            if (j < 5) xb = read_col(bo, j + 1, tn);
+            cn[j] = col_xf(xa);
+            asm volatile("" : "+v"(cn[j]));
+            xa = xb;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        row_xf(cn, v);
         __builtin_amdgcn_sched_barrier(0);
-        const float* r = sRaw + (k & 1) * W4_RAW;
-        // column transform: row `wave` of B^T d for the six patch columns of the lane's tile, ONE column in flight at a time (the
-        // register budget of three waves per SIMD has no room for more; the other waves of the SIMD cover the LDS latency)
-        f32x2 cl[6], ch[6];
-#pragma unroll
-        for (int bq = 0; bq < 6; ++bq) {
-            constexpr int OFFS[4] = {0, OFF1, OFF2, OFF3};
-            const int col = (OFFS[bq & 3] + (bq >> 2)) * 4;
-            const f32x4 da = *reinterpret_cast<const f32x4*>(r + oa + col);
-            const f32x4 db = *reinterpret_cast<const f32x4*>(r + ob + col);
-            const f32x4 dc = *reinterpret_cast<const f32x4*>(r + oc + col);
-            const f32x4 dd = *reinterpret_cast<const f32x4*>(r + od + col);
-            cl[bq] = __builtin_elementwise_fma(k0v, da.xy, __builtin_elementwise_fma(k1v, db.xy, __builtin_elementwise_fma(k2v, dc.xy, k3v * dd.xy)));
-            ch[bq] = __builtin_elementwise_fma(k0v, da.zw, __builtin_elementwise_fma(k1v, db.zw, __builtin_elementwise_fma(k2v, dc.zw, k3v * dd.zw)));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        const unsigned u_this = ubase + (unsigned)k * (W4_UV * 4u) + 8u;                   // second channel pair of this chunk
-        const unsigned u_next = ubase + (unsigned)(more ? k + 1 : k) * (W4_UV * 4u);       // past the end: a harmless re-load
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            // row transform along the six columns for channels 2 q, 2 q + 1 of the lane's quad: the A operands of 12 MFMAs
-            const f32x2 c0 = q ? ch[0] : cl[0], c1 = q ? ch[1] : cl[1], c2 = q ? ch[2] : cl[2];
-            const f32x2 c3 = q ? ch[3] : cl[3], c4 = q ? ch[4] : cl[4], c5 = q ? ch[5] : cl[5];
-            const f32x2 m4 = {-4.f, -4.f}, m5 = {-5.f, -5.f}, p4 = {4.f, 4.f}, p2 = {2.f, 2.f}, m2 = {-2.f, -2.f};
-            const f32x2 t1 = __builtin_elementwise_fma(m4, c2, c4), t2 = __builtin_elementwise_fma(m4, c1, c3);
-            const f32x2 t3 = c4 - c2, t4 = c3 - c1;
-            f32x2 v[6];
-            v[0] = __builtin_elementwise_fma(p4, c0, __builtin_elementwise_fma(m5, c2, c4));
-            v[1] = t1 + t2;
-            v[2] = t1 - t2;
-            v[3] = __builtin_elementwise_fma(p2, t4, t3);
-            v[4] = __builtin_elementwise_fma(m2, t4, t3);
-            v[5] = __builtin_elementwise_fma(p4, c1, __builtin_elementwise_fma(m5, c3, c5));
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][0], bu[j][0], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][1], bu[j][1], acc[j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                bu[j] = buf_load2(u_rsrc, uoff, (q == 0 ? u_this : u_next) + 1024u * j);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
     };
 
+    // ---- prologue: raw(0), raw(1) in flight; U of step 0; A operands of step 0 ----
     issue_raw(0, true);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) bu[j] = buf_load2(u_rsrc, uoff, ubase + 1024u * j);
+    for (int j = 0; j < 6; ++j) bu[j] = buf_load2(u_rsrc, uoff, ubase + 2048u * j);
     __builtin_amdgcn_sched_barrier(0);
-    for (int k = 0; k < nchunk; ++k) chunk_step(k);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          // the raw(0) pieces are older than the six U loads
+    raw_barrier();
+    issue_raw(1, nchunk > 1);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x2 v[6];
+    {
+        f32x2 c0[6];
+#pragma unroll
+        for (int bq = 0; bq < 6; ++bq) c0[bq] = col_xf(read_col(0, bq, 0));
+        row_xf(c0, v);
+    }
+#ifdef CF_STAMP
+    const long long t_loop_begin = __builtin_readcyclecounter();
+#endif
+    for (int k = 0; k < nchunk; ++k) {
+        const int bo = (k & 1) * (W4_RAW * 4), bn = ((k + 1) & 1) * (W4_RAW * 4);
+        const unsigned ub = ubase + (unsigned)k * (W4_UV * 4u);
+#ifdef CF_STAMP
+        const long long t0 = __builtin_readcyclecounter();
+#endif
+        step(v, bo, 1, ub + 512u);                  // (k, 0): builds (k, 1); bu <- U(k, 1)
+        step(v, bo, 2, ub + 1024u);                 // (k, 1)
+        step(v, bo, 3, ub + 1536u);                 // (k, 2)
+#ifdef CF_STAMP
+        const long long t1 = __builtin_readcyclecounter();
+#endif
+        // hand-off: raw(k+1) has landed (its pieces are older than the six U loads just issued), everybody is done with raw(k)
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        raw_barrier();
+#ifdef CF_STAMP
+        const long long t2 = __builtin_readcyclecounter();
+#endif
+        issue_raw(k & 1, k + 2 < nchunk);           // raw(k+2) into the buffer raw(k) just left
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef CF_STAMP
+        const long long t3 = __builtin_readcyclecounter();
+        st_s012 += t1 - t0; st_wait += t2 - t1; st_dma += t3 - t2;
+#endif
+        // (k, 3): builds (k+1, 0) from the next raw buffer (zeros past the end); bu <- U(k+1, 0) (past the end: a re-load)
+        step(v, bn, 0, k + 1 < nchunk ? ub + W4_UV * 4u : ub);
+    }
 
+#ifdef CF_STAMP
+    const long long t_loop_end = __builtin_readcyclecounter();
+    if (p.stamp && lane == 0) {      // [vmcnt wait + barrier, DMA issue, steps 0..2, prologue, chunks, loop, -, MHz] cycles of this wave
+        long long* q = p.stamp + ((long)blockIdx.x * 6 + wave) * 8;
+        q[0] = st_wait; q[1] = st_dma; q[2] = st_s012; q[3] = t_loop_begin - t_begin; q[4] = nchunk;
+        q[5] = t_loop_end - t_loop_begin;
+        const long long dr = (long long)__builtin_amdgcn_s_memrealtime() - r_begin;
+        q[7] = dr > 0 ? ((__builtin_readcyclecounter() - t_begin) * 100) / dr : 0;
+    }
+#endif
     __syncthreads();                                // every wave is done with the raw ring before it becomes the exchange buffer
     // ---- output transform.  Along j in registers, IN PLACE (acc[j'] <- sum_j A^T[j'][j] M[i][j], j' = 0..3); along i across the
     // waves through LDS, two output columns j' per round: X[i = wave][2][tile 32][cout 32] = 48 KB.  Waves 0..3 (= output row i')
@@ -259,6 +337,9 @@ __device__ __forceinline__ void wino4_body(const ConvParams& p, float* smem) {
                 }
         }
     }
+#ifdef CF_STAMP
+    if (p.stamp && lane == 0) p.stamp[((long)blockIdx.x * 6 + wave) * 8 + 6] = __builtin_readcyclecounter() - t_loop_end;   // exchange part of the tail
+#endif
     if (wave >= 4) return;                          // no barrier below this line
 #pragma unroll 1
     for (int jp = 0; jp < 4; ++jp) {
@@ -283,31 +364,36 @@ __device__ __forceinline__ void wino4_body(const ConvParams& p, float* smem) {
     }
 }
 
-__global__ __launch_bounds__(384, 3) void conv_wino4_kernel_wide(const ConvParams p) {
-    __shared__ __attribute__((aligned(16))) float smem[W4_SMEM];         // ONE __shared__ object: see conv_wino_kernel
-    wino4_body<0>(p, smem);
-}
-__global__ __launch_bounds__(384, 3) void conv_wino4_kernel_tall(const ConvParams p) {
-    __shared__ __attribute__((aligned(16))) float smem[W4_SMEM];
-    wino4_body<1>(p, smem);
+__global__ __launch_bounds__(384, 3) void conv_wino4_kernel(const ConvParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[W4_SMEM / 4];     // ONE __shared__ object: see conv_wino_kernel
+#ifdef CF_CENSUS
+    long long c0;
+    census_begin(p, c0);
+#endif
+    wino4_body(p, smem);
+#ifdef CF_CENSUS
+    census_end(p, c0);
+#endif
 }
 
-// U = G g G^T for F(4x4,3x3) of a packed direct matrix w [rows][tap][cin_pad], stored [n-block][chunk][pos = i*6+j][32 n][8 k];
-// computed in fp64 and rounded once; rows past `rows` are zero
+// U = G g G^T for F(4x4,3x3) of a packed direct matrix w [rows][tap][cin_pad], stored
+// [n-block][chunk of 16][pos = i*6+j][step t][32 n][lh][2] (channel = 16 chunk + 4 t + 2 lh + e: what lane (n, lh) of the owning wave
+// feeds to the two MFMAs of step t); computed in fp64 and rounded once; rows past `rows` are zero
 __global__ void wino4_weight_kernel(const float* __restrict__ w, float* __restrict__ u, int rows, int cin_pad, int nblk) {
-    const int nchunk = cin_pad / 8;
+    const int nchunk = cin_pad / W4_KC;
     const long total = (long)nblk * nchunk * W4_UV;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const int kk = (int)(idx & 7);
-    const int nl = (int)((idx >> 3) & 31);
-    const long rest = idx >> 8;
+    const int e = (int)(idx & 1), lh = (int)((idx >> 1) & 1);
+    const int nl = (int)((idx >> 2) & 31);
+    const int t = (int)((idx >> 7) & 3);
+    const long rest = idx >> 9;
     const int pos = (int)(rest % 36);
     const long blk = rest / 36;
     const int chunk = (int)(blk % nchunk);
     const int nb = (int)(blk / nchunk);
     const int n = nb * 32 + nl;
-    const int c = chunk * 8 + kk;
+    const int c = chunk * W4_KC + 4 * t + 2 * lh + e;
     float val = 0.f;
     if (n < rows) {
         const double G[6][3] = {{1.0 / 4, 0.0, 0.0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
@@ -323,16 +409,14 @@ __global__ void wino4_weight_kernel(const float* __restrict__ w, float* __restri
 }
 
 hipError_t launch_wino4_weights(const float* w, float* u, int rows, int cin_pad, hipStream_t s) {
-    if (!w || !u || rows <= 0 || cin_pad <= 0 || (cin_pad % 8) != 0) return hipErrorInvalidValue;
+    if (!w || !u || rows <= 0 || cin_pad <= 0 || (cin_pad % W4_KC) != 0) return hipErrorInvalidValue;
     const int nblk = (rows + 31) / 32;
-    const long total = (long)nblk * (cin_pad / 8) * W4_UV;
+    const long total = (long)nblk * (cin_pad / W4_KC) * W4_UV;
     hipLaunchKernelGGL(wino4_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, u, rows, cin_pad, nblk);
     return hipGetLastError();
 }
-long wino4_weight_floats(int rows, int cin_pad) { return (long)((rows + 31) / 32) * (cin_pad / 8) * W4_UV; }
-int wino4_regions(int Ho, int Wo) {
-    return wino4_tall(Ho, Wo) ? ((Ho + 31) / 32) * ((Wo + 15) / 16) : ((Ho + 15) / 16) * ((Wo + 31) / 32);
-}
+long wino4_weight_floats(int rows, int cin_pad) { return (long)((rows + 31) / 32) * (cin_pad / W4_KC) * W4_UV; }
+int wino4_regions(int Ho, int Wo) { return ((Ho + 15) / 16) * ((Wo + 31) / 32); }
 
 // F(4x4,3x3): same layer class as wino_ok, with its own transformed weights
 bool wino4_ok(const ConvParams& p) {
@@ -340,7 +424,7 @@ bool wino4_ok(const ConvParams& p) {
     if (p.Ho != p.Hin || p.Wo != p.Win || p.Hin < 12 || p.Win < 12) return false;
     if (p.w_bs != 0 && p.w_div <= 1) return false;
     for (int i = 0; i < p.nseg; ++i)
-        if (p.seg_c[i] % 8) return false;
+        if (p.seg_c[i] % W4_KC) return false;
     return dma_range_ok(p);
 }
 
@@ -349,8 +433,7 @@ hipError_t launch_wino4(const ConvParams& p, int batch, hipStream_t s) {
     const long wgs = (long)wino4_regions(p.Ho, p.Wo) * ((p.cout + 31) / 32) * batch;
     if (wgs <= 0 || wgs >= 0x7FFFFFFFL) return hipErrorInvalidValue;
     g_last_launch.threads = wgs * 384;
-    if (wino4_tall(p.Ho, p.Wo)) hipLaunchKernelGGL(conv_wino4_kernel_tall, dim3((unsigned)wgs), dim3(384), 0, s, p);
-    else hipLaunchKernelGGL(conv_wino4_kernel_wide, dim3((unsigned)wgs), dim3(384), 0, s, p);
+    hipLaunchKernelGGL(conv_wino4_kernel, dim3((unsigned)wgs), dim3(384), 0, s, p);
     return hipGetLastError();
 }
 

@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch  # noqa: E402
 
-buf = torch.zeros(8 * 4 * 40000, dtype=torch.int64, device="cuda")
+buf = torch.zeros(8 * 6 * 40000, dtype=torch.int64, device="cuda")
 os.environ["CF_STAMP_BUF"] = str(buf.data_ptr())
 import conv_bench  # noqa: E402
 
@@ -34,6 +34,11 @@ for case in CASES.split(","):
     n = d[:, 4].mean().item()
     m = d.mean(0)
     comp = (m[5] - m[0] - m[1] - m[2]) / n
+    if int(tile) == 42:     # conv_wino4_kernel: [vmcnt wait + barrier, DMA issue, steps 0..2, prologue, chunks, loop, exchange, MHz]
+        print("%-34s tile 42  %7.1f us %5.1f TF | chunks %3d | per chunk: steps0-2 %6.0f  wait+barrier %6.0f  dma issue %5.0f  step3 %6.0f"
+              " | prologue %6.0f  loop %7.0f  exchange %6.0f cycles | shader clock %4.0f MHz" % (
+                  shape[0], r[0], r[1], n, m[2] / n, m[0] / n, m[1] / n, (m[5] - m[0] - m[1] - m[2]) / n, m[3], m[5], m[6], m[7]), flush=True)
+        continue
     if int(tile) == 40:     # conv_wino_kernel: [DMA wait + first barrier, second barrier, issue + input transform]
         print("%-34s tile 40  %7.1f us %5.1f TF | chunks %3d | per chunk: dma-wait+barrier %4.0f  issue+transform %4.0f  barrier %4.0f  "
               "frag reads + 16 mfma %4.0f | prologue %6.0f  loop %7.0f  tail %6.0f cycles | shader clock %4.0f MHz" % (
