@@ -1,5 +1,15 @@
 // conv_wino4.hip -- Winograd F(4x4,3x3) convolution kernel (round 3) and its weight transform; launched through launch_conv
 // (conv_igemm.hip) as tile 42.  gfx950 only.
+//
+// STATUS: parity-green (tests/test_ops_gpu.py::test_conv_winograd_f4x4) and OPT-IN (CF_WINO4_MIN=<workgroups>; explicit tile 42).
+// Measured on MI355X (tools/conv_bench.py, profiles/r03_wino4_*.txt): 1.04-1.05x the F(2x2,3x3) kernel on the 192->256 gate
+// convolution (180x240 B=8: 348 vs 364 us; 480x640 B=4: 1090 vs 1142 us), 0.7-0.9x on the 64- and 128-channel layers, whose 4-12
+// chunk loops do not amortise its prologue + tail (13 k + 22 k cycles per workgroup) -- so the launcher does not pick it by
+// default.  Per chunk a wave spends 15.6 k cycles on 48 MFMAs (3.1 k cycles of the matrix pipe) with three waves per SIMD:
+// the matrix pipe is ~0.59 busy inside the loop (tools/stamp_probe.py), against ~1.0 for conv_wino_kernel's loop, i.e. the
+// 1.78x fewer MFMAs are spent again on exposed LDS latency of the in-order 4-row column reads and on the barrier skew of
+// twelve waves.  What the way here established: a six-wave workgroup at > 128 VGPRs gets ONE slot per CU
+// (tools/census_probe.py); 16 bytes per lane from 64 different cache lines bind an LDS-DMA gather to the L1-fill path.
 #include "conv_common.h"
 
 namespace cf {
@@ -12,8 +22,8 @@ namespace cf {
 // network on the CPU oracle against the reference goldens BEFORE this kernel was written: worst 2.1e-5 with EVERY
 // 3x3 / stride-1 layer replaced; the regression bar of the tests is 2e-4, the contract 1e-3).
 //
-// One workgroup = 6 waves (384 threads) = a region of 4 x 8 tiles (16 x 32 output pixels) x 32 output channels; K = Cin in
-// chunks of 16 channels:
+// One six-wave group = a region of 4 x 8 tiles (16 x 32 output pixels) x 32 output channels (a workgroup holds two such groups, see
+// wino4_body); K = Cin in chunks of 16 channels:
 //   raw    the (18 x 34 pixel) x 16-channel input patch of a chunk, LDS-DMA'd from the NHWC tensor (reflect / zero padding
 //          resolved in the per-lane source offset once per workgroup), double buffered.  FOUR consecutive lanes of a DMA
 //          instruction fetch the four channel quads of one patch cell = 64 contiguous bytes: an instruction touches 16 cache
@@ -28,13 +38,16 @@ namespace cf {
 //          scalars: 4 d0 - 5 d2 + d4 | d4 - 4 d2 +- (d3 - 4 d1) | d4 - d2 +- 2 (d3 - d1) | 4 d1 - 5 d3 + d5): lane (tile, pair)
 //          reads 4 rows x 6 pixels (ds_read_b64 straight from the raw patch), then applies the row transform along the 6
 //          columns in registers.  Software pipeline: the A operands of step s + 1 are built in the shadow of the 12 MFMAs of
-//          step s (column j right behind position j's MFMAs), inside 168 registers = three waves per SIMD = two workgroups per CU;
+//          step s (column j right behind position j's MFMAs), inside 168 registers = three waves per SIMD;
 //   U      = G g G^T (fp64 at weight-pack time, rounded once), [n-block][chunk][36 pos][4 steps][32 n][2][2]: the 64 lanes of
 //          a load read 512 contiguous bytes; every lane loads its own B fragments one step ahead, behind that position's MFMAs;
 //   tail   A^T . A is separable: along j in registers (6 -> 4), along i across the six waves through LDS (two output
 //          columns j' per round); waves 0..3 each finish output row i' of every tile as four 32-row patches through the
 //          common fused epilogue (patch_tail with a row -> pixel table) once the accumulators are dead.
 // ---------------------------------------------------------------------------------------------------------
+#ifndef W4_ABL
+#define W4_ABL 0                                             // ablation builds (tools/build_variant.sh ... -DW4_ABL=n): 8 = no raw DMA
+#endif
 static constexpr int W4_KC = 16;                             // channels per chunk
 static constexpr int W4_CELLS = 18 * 34;                     // patch cells (612)
 static constexpr int W4_NDMA = (W4_CELLS * 4 + 63) / 64;     // wave-instructions of LDS-DMA per chunk (39; the last one has 48 dead slots)
@@ -42,7 +55,7 @@ static constexpr int W4_RAW = W4_NDMA * 64 * 4;              // floats per raw b
 static constexpr int W4_UV = 36 * 4 * 32 * 4;                // floats of a chunk's U block (18432)
 static constexpr int W4_X = 6 * 2 * 32 * 32;                 // floats of the cross-wave exchange buffer of the tail (48 KB)
 static constexpr int W4_TAIL = W4_X + 4 * 32 * EPI_S + 4 * 32;   // + four epilogue patches + their row -> pixel tables (floats)
-static constexpr int W4_SMEM = 4 * (2 * W4_RAW > W4_TAIL ? 2 * W4_RAW : W4_TAIL);   // bytes: 79,872 -> two workgroups per CU (159,744 of 163,840)
+static constexpr int W4_SMEM = 4 * (2 * W4_RAW > W4_TAIL ? 2 * W4_RAW : W4_TAIL);   // bytes per six-wave group: 79,872 (a workgroup = two groups = 159,744 of 163,840)
 
 __device__ __forceinline__ void wino4_body(const ConvParams& p, float* smem) {
 #ifdef CF_STAMP
@@ -54,14 +67,22 @@ __device__ __forceinline__ void wino4_body(const ConvParams& p, float* smem) {
     constexpr int RH = 16, RW = 32;                          // region size in output pixels
     constexpr int PC = 34;                                   // patch columns (18 rows)
     constexpr int OFF1 = 9, OFF2 = 18, OFF3 = 26;            // first cell of column class px mod 4 = 1, 2, 3 within a patch row (9 + 9 + 8 + 8 columns)
-    float* const sRaw = smem;
 
+    // A workgroup is TWELVE waves = two independent six-wave groups (two neighbouring regions, the same 32 output channels), each with
+    // its own half of the LDS: a six-wave workgroup lands 2, 2, 1, 1 on the four SIMDs, so at three waves per SIMD a second one never
+    // fits beside it (measured with tools/census_probe.py: one resident workgroup per CU); twelve waves land 3, 3, 3, 3.  The groups
+    // only share the barriers.
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave12 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave12 >= 6 ? 1 : 0;
+    const int wave = wave12 - 6 * grp;
+    smem += grp * (W4_SMEM / 4);
+    float* const sRaw = smem;
     const int Ho = p.Ho, Wo = p.Wo;
     const int nrx = (Wo + RW - 1) / RW, nry = (Ho + RH - 1) / RH;
     const int nreg = nrx * nry;
+    const int npair = (nreg + 1) / 2;
     const int nt = (p.cout + 31) / 32;
     int tile_id = blockIdx.x;
     if (p.sched == 1) {
@@ -72,8 +93,10 @@ __device__ __forceinline__ void wino4_body(const ConvParams& p, float* smem) {
     }
     const int nblk = tile_id % nt;
     const int rest = tile_id / nt;
-    const int reg = rest % nreg;
-    const int b = rest / nreg;
+    const int reg_raw = 2 * (rest % npair) + grp;
+    const bool dead = reg_raw >= nreg;              // odd region count: the last pair's second group computes on zeros and stores nothing
+    const int reg = dead ? nreg - 1 : reg_raw;
+    const int b = rest / npair;
     const int oy0 = (reg / nrx) * RH, ox0 = (reg % nrx) * RW;
     const int n0 = nblk * 32;
 
@@ -91,7 +114,7 @@ __device__ __forceinline__ void wino4_body(const ConvParams& p, float* smem) {
         const int f = ((u >> 2) & 1) | (((py >> 2) & 1) << 1);
         const int quad = (sl & 3) ^ f;
         int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
-        bool ok = c < W4_CELLS && iy <= p.Hin && ix <= p.Win;       // beyond the halo of the last row / column: unused
+        bool ok = !dead && c < W4_CELLS && iy <= p.Hin && ix <= p.Win;       // beyond the halo of the last row / column: unused
         if (p.pad_mode == 1) {
             iy = reflect_idx(iy, p.Hin);
             ix = reflect_idx(ix, p.Win);
@@ -109,22 +132,29 @@ __device__ __forceinline__ void wino4_body(const ConvParams& p, float* smem) {
     int it_seg = 0, it_cs = 0;
     const float* seg_base = p.in[0] + (long)b * p.seg_bs[0];
     int seg_ld = p.seg_ld[0], seg_cn = p.seg_c[0];
-    // dead slots and the chunks past the end fetch out of range (= zeros into LDS): the issue pattern never changes
-    auto issue_raw = [&](int buf, bool live) __attribute__((always_inline)) {
-        const __amdgpu_buffer_rsrc_t rs = make_rsrc(seg_base);
-        const unsigned ld4 = (unsigned)seg_ld * 4u, so = (unsigned)it_cs * 4u;
-        float* rbase = sRaw + buf * W4_RAW;
-#pragma unroll
-        for (int j = 0; j < 7; ++j) {
-            if (wave + 6 * j < W4_NDMA) {           // wave-uniform: the seventh piece exists for waves 0..2 only
-                unsigned w = a_src[j >> 1];
-                asm volatile("" : "+v"(w));         // decode HERE, per chunk: hoisted out of the loop the seven decoded offsets would spill
-                const unsigned d = (w >> (16 * (j & 1))) & 0xFFFFu;
-                const int pix = pix0 + (int)(d & 63u) * p.Win + (int)((d >> 6) & 127u);
-                const unsigned off = ((d & 0x8000u) || !live) ? BUF_OOB : (unsigned)pix * ld4 + ((d >> 13) & 3u) * 16u;
-                dma16_to_lds(rs, rbase + 64 * (wave + 6 * j) * 4, off, so);
-            }
+    // dead slots and the chunks past the end fetch out of range (= zeros into LDS): the issue pattern never changes.  The pieces of a
+    // chunk are issued one at a time (issue_piece) so that the main loop can tuck them between its MFMAs.
+    auto issue_piece = [&](int j, int buf, bool live) __attribute__((always_inline)) {
+        // pieces 0..5 exist for every wave and are issued UNCONDITIONALLY: behind a branch the compiler's vmcnt bookkeeping assumes the
+        // piece may be missing and waits for the slow gather in front of the next MFMAs; the seventh piece exists for waves 0..2 only
+        static_assert(5 + 6 * 5 < W4_NDMA && 6 * 6 + 3 == W4_NDMA, "39 pieces over six waves");
+        if (j < 6 || wave < 3) {
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(seg_base);
+            unsigned w = a_src[j >> 1];
+            asm volatile("" : "+v"(w));             // decode HERE, per chunk: hoisted out of the loop the seven decoded offsets would spill
+            const unsigned d = (w >> (16 * (j & 1))) & 0xFFFFu;
+            // 24-bit multiplies (full rate; the 32-bit forms are quarter rate and this runs in the MFMA shadow): row < 64, Win < 2^24,
+            // pixel index < 2^24 (wino4_ok), pixel stride in bytes < 2^24
+            const unsigned pix = (unsigned)pix0 + __umul24(d & 63u, (unsigned)p.Win) + ((d >> 6) & 127u);
+            const unsigned off = ((d & 0x8000u) || !live) ? BUF_OOB : __umul24(pix, (unsigned)seg_ld * 4u) + ((d >> 13) & 3u) * 16u;
+#if !(W4_ABL & 8)
+            dma16_to_lds(rs, sRaw + buf * W4_RAW + 64 * (wave + 6 * j) * 4, off, (unsigned)it_cs * 4u);
+#else
+            if (off == 12345u) smem[0] = 1.f;
+#endif
         }
+    };
+    auto next_chunk = [&]() __attribute__((always_inline)) {
         it_cs += W4_KC;
         if (it_cs >= seg_cn) {
             it_cs = 0;
@@ -135,6 +165,11 @@ __device__ __forceinline__ void wino4_body(const ConvParams& p, float* smem) {
                 seg_cn = it_seg == 1 ? p.seg_c[1] : p.seg_c[2];
             }
         }
+    };
+    auto issue_raw = [&](int buf, bool live) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) issue_piece(j, buf, live);
+        next_chunk();
     };
 
     f32x16 acc[6];
@@ -207,7 +242,9 @@ __device__ __forceinline__ void wino4_body(const ConvParams& p, float* smem) {
     };
     // one step: the 12 MFMAs on (v, bu) with the transform of the NEXT step (raw buffer at byte offset bo, quad tn) in their shadow;
     // u_off = scalar byte offset of the U block that refills bu (the next step's)
-    auto step = [&](f32x2 (&v)[6], int bo, int tn, unsigned u_off) __attribute__((always_inline)) {
+    // dma_buf >= 0: the raw pieces of the chunk after next go out between the MFMA groups as well (after the hand-off barrier every
+    // wave used to issue its seven pieces back to back with the matrix pipe empty: 2.2 k cycles per chunk)
+    auto step = [&](f32x2 (&v)[6], int bo, int tn, unsigned u_off, int dma_buf, bool dma_live) __attribute__((always_inline)) {
         f32x2 cn[6];
         Col xa = read_col(bo, 0, tn), xb;
 #pragma unroll
@@ -218,6 +255,10 @@ __device__ __forceinline__ void wino4_body(const ConvParams& p, float* smem) {
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][0], bu[j][0], acc[j], 0, 0, 0);
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][1], bu[j][1], acc[j], 0, 0, 0);
             bu[j] = buf_load2(u_rsrc, uoff, u_off + 2048u * j);
+            if (dma_buf >= 0) {
+                issue_piece(j, dma_buf, dma_live);
+                if (j == 5) issue_piece(6, dma_buf, dma_live);
+            }
             if (j < 5) xb = read_col(bo, j + 1, tn);
             cn[j] = col_xf(xa);
             asm volatile("" : "+v"(cn[j]));
@@ -225,6 +266,7 @@ __device__ __forceinline__ void wino4_body(const ConvParams& p, float* smem) {
             __builtin_amdgcn_sched_barrier(0);
         }
         row_xf(cn, v);
+        if (dma_buf >= 0) next_chunk();
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -254,9 +296,9 @@ __device__ __forceinline__ void wino4_body(const ConvParams& p, float* smem) {
 #ifdef CF_STAMP
         const long long t0 = __builtin_readcyclecounter();
 #endif
-        step(v, bo, 1, ub + 512u);                  // (k, 0): builds (k, 1); bu <- U(k, 1)
-        step(v, bo, 2, ub + 1024u);                 // (k, 1)
-        step(v, bo, 3, ub + 1536u);                 // (k, 2)
+        step(v, bo, 1, ub + 512u, -1, false);       // (k, 0): builds (k, 1); bu <- U(k, 1)
+        step(v, bo, 2, ub + 1024u, -1, false);      // (k, 1)
+        step(v, bo, 3, ub + 1536u, -1, false);      // (k, 2)
 #ifdef CF_STAMP
         const long long t1 = __builtin_readcyclecounter();
 #endif
@@ -266,20 +308,19 @@ __device__ __forceinline__ void wino4_body(const ConvParams& p, float* smem) {
 #ifdef CF_STAMP
         const long long t2 = __builtin_readcyclecounter();
 #endif
-        issue_raw(k & 1, k + 2 < nchunk);           // raw(k+2) into the buffer raw(k) just left
-        __builtin_amdgcn_sched_barrier(0);
 #ifdef CF_STAMP
         const long long t3 = __builtin_readcyclecounter();
         st_s012 += t1 - t0; st_wait += t2 - t1; st_dma += t3 - t2;
 #endif
         // (k, 3): builds (k+1, 0) from the next raw buffer (zeros past the end); bu <- U(k+1, 0) (past the end: a re-load)
-        step(v, bn, 0, k + 1 < nchunk ? ub + W4_UV * 4u : ub);
+        // raw(k+2) goes into the buffer raw(k) just left, piece by piece between this step's MFMAs
+        step(v, bn, 0, k + 1 < nchunk ? ub + W4_UV * 4u : ub, k & 1, k + 2 < nchunk);
     }
 
 #ifdef CF_STAMP
     const long long t_loop_end = __builtin_readcyclecounter();
     if (p.stamp && lane == 0) {      // [vmcnt wait + barrier, DMA issue, steps 0..2, prologue, chunks, loop, -, MHz] cycles of this wave
-        long long* q = p.stamp + ((long)blockIdx.x * 6 + wave) * 8;
+        long long* q = p.stamp + ((long)blockIdx.x * 12 + wave12) * 8;
         q[0] = st_wait; q[1] = st_dma; q[2] = st_s012; q[3] = t_loop_begin - t_begin; q[4] = nchunk;
         q[5] = t_loop_end - t_loop_begin;
         const long long dr = (long long)__builtin_amdgcn_s_memrealtime() - r_begin;
@@ -338,7 +379,7 @@ __device__ __forceinline__ void wino4_body(const ConvParams& p, float* smem) {
         }
     }
 #ifdef CF_STAMP
-    if (p.stamp && lane == 0) p.stamp[((long)blockIdx.x * 6 + wave) * 8 + 6] = __builtin_readcyclecounter() - t_loop_end;   // exchange part of the tail
+    if (p.stamp && lane == 0) p.stamp[((long)blockIdx.x * 12 + wave12) * 8 + 6] = __builtin_readcyclecounter() - t_loop_end;   // exchange part of the tail
 #endif
     if (wave >= 4) return;                          // no barrier below this line
 #pragma unroll 1
@@ -351,21 +392,21 @@ __device__ __forceinline__ void wino4_body(const ConvParams& p, float* smem) {
         if (lane < 32) {
             const int ty = lane / TWr, tx = lane - ty * TWr;
             const int oy = oy0 + 4 * ty + wave, ox = ox0 + 4 * tx + jp;
-            mtab[lane] = (oy < Ho && ox < Wo) ? oy * Wo + ox : -1;
+            mtab[lane] = (!dead && oy < Ho && ox < Wo) ? oy * Wo + ox : -1;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         patch_tail(p, sW, b, 0, n0, lane, Ho * Wo, 0, 4, 1, 0, mtab);
-        if (p.st_partial) patch_stats(p, sW, b, 0, n0, lane, Ho * Wo, mtab, reg * 16 + wave * 4 + jp, nreg * 16);
+        if (p.st_partial && !dead) patch_stats(p, sW, b, 0, n0, lane, Ho * Wo, mtab, reg * 16 + wave * 4 + jp, nreg * 16);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();            // the patch and its table are rewritten by the next column
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
-__global__ __launch_bounds__(384, 3) void conv_wino4_kernel(const ConvParams p) {
-    __shared__ __attribute__((aligned(16))) float smem[W4_SMEM / 4];     // ONE __shared__ object: see conv_wino_kernel
+__global__ __launch_bounds__(768, 3) void conv_wino4_kernel(const ConvParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * W4_SMEM / 4]; // ONE __shared__ object (see conv_wino_kernel): 159,744 of the CU's 163,840 bytes
 #ifdef CF_CENSUS
     long long c0;
     census_begin(p, c0);
@@ -422,18 +463,19 @@ int wino4_regions(int Ho, int Wo) { return ((Ho + 15) / 16) * ((Wo + 31) / 32); 
 bool wino4_ok(const ConvParams& p) {
     if (p.a_mode != A_NHWC || p.prec != 0 || !p.w_wino4 || p.KH != 3 || p.KW != 3 || p.stride != 1 || p.padT != 1 || p.padL != 1) return false;
     if (p.Ho != p.Hin || p.Wo != p.Win || p.Hin < 12 || p.Win < 12) return false;
+    if ((long)p.Hin * p.Win >= (1L << 24)) return false;           // 24-bit pixel arithmetic in the raw-patch DMA
     if (p.w_bs != 0 && p.w_div <= 1) return false;
     for (int i = 0; i < p.nseg; ++i)
-        if (p.seg_c[i] % W4_KC) return false;
+        if (p.seg_c[i] % W4_KC || p.seg_ld[i] * 4L >= (1L << 24)) return false;
     return dma_range_ok(p);
 }
 
 hipError_t launch_wino4(const ConvParams& p, int batch, hipStream_t s) {
     if (!wino4_ok(p)) return hipErrorInvalidValue;
-    const long wgs = (long)wino4_regions(p.Ho, p.Wo) * ((p.cout + 31) / 32) * batch;
+    const long wgs = (long)((wino4_regions(p.Ho, p.Wo) + 1) / 2) * ((p.cout + 31) / 32) * batch;       // two regions per workgroup
     if (wgs <= 0 || wgs >= 0x7FFFFFFFL) return hipErrorInvalidValue;
-    g_last_launch.threads = wgs * 384;
-    hipLaunchKernelGGL(conv_wino4_kernel, dim3((unsigned)wgs), dim3(384), 0, s, p);
+    g_last_launch.threads = wgs * 768;
+    hipLaunchKernelGGL(conv_wino4_kernel, dim3((unsigned)wgs), dim3(768), 0, s, p);
     return hipGetLastError();
 }
 

@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch  # noqa: E402
 
-buf = torch.zeros(8 * 6 * 40000, dtype=torch.int64, device="cuda")
+buf = torch.zeros(8 * 12 * 40000, dtype=torch.int64, device="cuda")
 os.environ["CF_STAMP_BUF"] = str(buf.data_ptr())
 import conv_bench  # noqa: E402
 
