@@ -853,6 +853,7 @@ extern "C" int cf_create(cf_handle** out, const cf_config* cfg) {
     if (const char* e = getenv("CF_ENC_PAIR")) h->enc_pair = atoi(e) != 0;      // before the arena is laid out
     if (const char* e = getenv("CF_WINO")) h->wino = atoi(e) != 0;
     if (const char* e = getenv("CF_WINO4")) h->wino4 = atoi(e) != 0;
+    g_wino4_min = getenv("CF_WINO4_MIN") ? atol(getenv("CF_WINO4_MIN")) : 0;
     if (const char* e = getenv("CF_ARENA_SKEW")) h->arena.skew = (size_t)atol(e) & ~size_t(255);
     if (const char* e = getenv("CF_ARENA_ALIGN")) {
         const size_t a = (size_t)atol(e);

@@ -23,6 +23,7 @@
 namespace cf {
 
 thread_local LaunchInfo g_last_launch = {"", 0};
+long g_wino4_min = 0;
 
 // waves per SIMD the register allocation must leave room for (see conv_dma_kernel): what the main loop needs
 // (5 / 4 / 3 / 3 for 1 / 2 / 3 / 4 accumulator sub-tiles), capped by the LDS footprint of the two stage buffers
@@ -1821,7 +1822,7 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
     if ((tile == 0 || (auto_tile && tile == 40)) && wino4_ok(p)) {
         const long tb = p.tile_batch > 0 ? p.tile_batch : batch;
         const long wg = (long)wino4_regions(p.Ho, p.Wo) * ((p.cout + 31) / 32) * tb;
-        static const long w4min = getenv("CF_WINO4_MIN") ? atol(getenv("CF_WINO4_MIN")) : 0;
+        const long w4min = g_wino4_min;             // cf_create reads CF_WINO4_MIN (0 = never: the default)
         if (w4min > 0 && wg >= w4min) tile = 42;
     }
     if (tile == 0) {

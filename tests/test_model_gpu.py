@@ -644,3 +644,28 @@ def test_direct_conv_path_golden(gpu, monkeypatch, name, kind):
             assert gu.rel_err(gu.sub(outs[wino][t][2].cpu()), g["z_%d" % t]) < TOL, (wino, t)
     for a, b in zip(outs["0"], outs["1"]):
         assert gu.rel_err(a[0].cpu(), b[0].cpu()) < 1e-4 and gu.rel_err(a[2].cpu(), b[2].cpu()) < 1e-4
+
+
+@pytest.mark.parametrize("name,kind", [("eiflow_100x124.npz", "eiflow"), ("eiflow_180x240.npz", "eiflow")])
+def test_winograd_f4x4_path_golden(gpu, monkeypatch, name, kind):
+    """CF_WINO4_MIN=1: every 3x3 / stride-1 convolution with 16-channel segments on the opt-in F(4x4,3x3) kernel (conv_wino4_kernel)
+    through the whole recurrent network -- the reference goldens hold at the unchanged 2e-4 (the CPU study that preceded the kernel
+    predicted 2e-5)."""
+    g = gu.load(name)
+    H, W, B, frames, seed = [int(v) for v in g["meta"]]
+    monkeypatch.setenv("CF_WINO4_MIN", "1")
+    m = _build(kind, H, W, seed, gpu)
+    evs = [torch.from_numpy(g["ev_%d" % t]).to(gpu) for t in range(frames)]
+    with torch.no_grad():
+        out = _drive(kind, m, evs, None, gpu)
+    worst = 0.0
+    for t in range(frames):
+        for got, ref in ((out[t][0].cpu(), g["I_%d" % t]), (out[t][1].cpu(), g["flow_%d" % t]), (gu.sub(out[t][2].cpu()), g["z_%d" % t])):
+            worst = max(worst, gu.rel_err(got, ref))
+    assert worst < TOL, worst
+    monkeypatch.delenv("CF_WINO4_MIN")
+    m2 = _build(kind, H, W, seed, gpu)              # a new handle: back on the default kernels
+    with torch.no_grad():
+        out2 = _drive(kind, m2, evs, None, gpu)
+    assert not torch.equal(out2[-1][0], out[-1][0])          # the F(4x4,3x3) path really ran (results differ in the last bits)
+    assert gu.rel_err(out2[-1][0].cpu(), out[-1][0].cpu()) < 1e-4
