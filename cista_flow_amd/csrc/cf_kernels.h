@@ -123,6 +123,10 @@ long wino_weight_floats(int rows, int cin_pad);
 // the same for F(4x4,3x3) (conv_wino4_kernel's [n-block][chunk][36 pos][32 n][8 k] layout)
 hipError_t launch_wino4_weights(const float* w, float* u, int rows, int cin_pad, hipStream_t s);
 long wino4_weight_floats(int rows, int cin_pad);
+// conv_patch.hip, reached through launch_conv (tile 43): planar small-Cin inputs (A_GATHER) with an LDS-resident input patch
+bool patch_ok(const ConvParams& p);
+int patch_tiles(int Ho, int Wo);
+hipError_t launch_patch(const ConvParams& p, int batch, hipStream_t s);
 extern long g_wino4_min;   // launches with at least this many F(4x4,3x3) workgroups take tile 42 (0 = never; CF_WINO4_MIN at cf_create)
 // conv_wino4.hip, reached through launch_conv (tile 42)
 bool wino4_ok(const ConvParams& p);

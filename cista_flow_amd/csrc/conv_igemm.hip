@@ -1436,6 +1436,7 @@ static int wino_regions(int Ho, int Wo) {
 int conv_stats_chunks(const ConvParams& p, int tile) {
     if (tile == 40 || tile == 41) return wino_regions(p.Ho, p.Wo) * 4;
     if (tile == 42) return wino4_regions(p.Ho, p.Wo) * 16;
+    if (tile == 43) return patch_tiles(p.Ho, p.Wo) * 4;
     return (p.Ho * p.Wo + 31) / 32;
 }
 
@@ -1722,6 +1723,7 @@ const char* conv_tile_name(int tile) {
         case 40: return "conv_wino_kernel";
         case 41: return "conv_wino8_kernel";
         case 42: return "conv_wino4_kernel";
+        case 43: return "conv_patch_kernel";
         default: return "?";
     }
 }
@@ -1802,6 +1804,14 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
     }
     const bool auto_tile = tile == 0;
     if (tile == 0 && smalln_ok(p)) tile = 7;
+    // planar small-Cin inputs (encoder stems, We / Wi, the flow branch's 7x7): CF_PATCH=1 takes the LDS-resident patch kernel
+    // (conv_patch.hip) instead of the per-element gather of conv_igemm_kernel.  Off by default: measured equal on the 7x7 stems
+    // (66-68 us for the 5-channel one on BOTH kernels: 24 us of it is the fp32 MFMA floor of K = 245, the rest prologue, epilogue and
+    // exposed latency of a single under-filled round) and slower on We / Wi (31 vs 22 us)
+    if (tile == 0 && p.a_mode == A_GATHER && patch_ok(p)) {
+        static const int use_patch = getenv("CF_PATCH") ? atoi(getenv("CF_PATCH")) : 0;
+        if (use_patch) tile = 43;
+    }
     if (tile == 7 || tile == 15) {
         if (!smalln_ok(p)) return hipErrorInvalidValue;
         if (tile_used) *tile_used = 7;
@@ -1876,7 +1886,8 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
                 tile = wgs128x128 >= 2304 ? 25 : ((p.cout >= 256 && p.cout % 128 == 0) ? 28 : 23);
         }
     }
-    if (tile >= 20 && tile <= 42 && !(p.a_mode == A_NHWC && dma_range_ok(p))) return hipErrorInvalidValue;   // explicit DMA tile, image too large
+    if (tile >= 20 && tile <= 42 && !(p.a_mode == A_NHWC && dma_range_ok(p))) return hipErrorInvalidValue;
+    if (tile == 43 && !patch_ok(p)) return hipErrorInvalidValue;   // explicit DMA tile, image too large
     if (tile_used) *tile_used = tile;
     g_last_launch.kernel = conv_tile_name(tile);
     if (p.prec != 0 && p.prec != 1 && p.prec != 3) return hipErrorInvalidValue;
@@ -1920,6 +1931,7 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
         case 40: return launch_wino(p, batch, s);
         case 41: return launch_wino8(p, batch, s);
         case 42: return launch_wino4(p, batch, s);
+        case 43: return launch_patch(p, batch, s);
         default: return hipErrorInvalidValue;
     }
 }

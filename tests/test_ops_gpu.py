@@ -141,6 +141,8 @@ STATS_CASES = [
     (64, 64, 3, 3, 1, 1, 0, 40, 48, 64),     # Winograd tile: one partial per tile row of an 8 x 16 region
     (96, 96, 3, 3, 1, 1, 0, 40, 21, 37),     # ... ragged regions
     (64, 128, 3, 3, 1, 1, 0, 41, 21, 37),    # eight-wave Winograd tile
+    (1, 64, 7, 7, 2, 3, 2, 43, 37, 53),      # patch kernel (planar small-Cin input), ragged tiles
+    (5, 64, 7, 7, 2, 3, 2, 43, 64, 80),
     (64, 64, 3, 3, 1, 1, 0, 42, 48, 64),     # F(4x4,3x3): sixteen partials per 32-tile region
     (96, 96, 3, 3, 1, 1, 0, 42, 21, 37),     # ... ragged regions
     (64, 160, 3, 3, 1, 1, 0, 42, 17, 17),    # ... a small ragged map with B * Cout > 128 (partial-buffer sizing)
@@ -266,15 +268,23 @@ def test_conv_epilogue_activation(gpu, epi):
 @pytest.mark.parametrize("case", [(5, 32, 3, 1, 1, 1), (1, 32, 3, 1, 1, 1), (1, 64, 7, 2, 3, 0), (5, 64, 7, 2, 3, 0),
                                   (2, 128, 7, 1, 3, 0)])
 def test_conv_gather_small_cin(gpu, case):
+    """Planar small-Cin inputs (encoder stems, We / Wi, convf1): the per-element gather of conv_igemm_kernel (what the launcher
+    picks, and explicit tile 2) and the opt-in LDS-resident patch kernel (tile 43) against F.conv2d -- ragged sizes, one tile and
+    many, fused ReLU."""
     Cin, Cout, K, stride, pad, pad_mode = case
     g = torch.Generator().manual_seed(11 + Cin + K)
-    B, H, W = 2, 22, 30
-    x = torch.randn(B, Cin, H, W, generator=g)
-    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
-    b = torch.randn(Cout, generator=g)
-    ref = ref_conv(x, w, b, stride, pad, pad, pad_mode)
-    got = run_conv(gpu, x, w, b, stride, pad, pad, pad_mode, 2, 0, 0, ref.shape[2], ref.shape[3])
-    assert (got - ref).abs().max().item() < 1e-4
+    for (B, H, W, epi) in ((2, 22, 30, 0), (3, 37, 53, 1), (1, 9, 16, 0), (2, 64, 80, 0)):
+        if pad_mode == 1 and min(H, W) <= pad:
+            continue
+        x = torch.randn(B, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+        b = torch.randn(Cout, generator=g)
+        ref = ref_conv(x, w, b, stride, pad, pad, pad_mode)
+        if epi == 1:
+            ref = torch.relu(ref)
+        for tile in (0, 43, 2):
+            got = run_conv(gpu, x, w, b, stride, pad, pad, pad_mode, 2, epi, tile, ref.shape[2], ref.shape[3])
+            assert got.shape == ref.shape and (got - ref).abs().max().item() < 1e-4, (B, H, W, tile)
 
 
 def test_conv_fused_upsample(gpu):
