@@ -369,12 +369,15 @@ hipError_t launch_inorm_stats(const float* x, int ld, long bs, int B, int HW, in
 // number of doubles launch_inorm_stats needs in `partial`
 long inorm_partial_doubles(int B, int HW, int C) { return (long)B * ((HW + IN_CHUNK - 1) / IN_CHUNK) * C * 2; }
 // ... and a convolution with fused statistics (ConvParams::st_partial, 32-pixel patches)
-// per image max(32-pixel patches, 4 partials per Winograd region in either orientation of the 8 x 16 regions): on small ragged
+// per image max(32-pixel patches, 4 partials per Winograd region in either orientation of the 8 x 16 regions, 16 per F(4x4,3x3) region): on small ragged
 // maps the regions outnumber the patches (17 x 17: 24 partials against 10), so the bound is taken from (Ho, Wo), not from Ho*Wo
 long inorm_patch_doubles(int B, int Ho, int Wo, int C) {
     const long patches = ((long)Ho * Wo + 31) / 32;
     const long wide = 4L * ((Ho + 7) / 8) * ((Wo + 15) / 16), tall = 4L * ((Ho + 15) / 16) * ((Wo + 7) / 8);
-    const long chunks = patches > wide ? (patches > tall ? patches : tall) : (wide > tall ? wide : tall);
+    const long w4 = 16L * ((Ho + 15) / 16) * ((Wo + 31) / 32);          // conv_wino4_kernel: 16 partials per 16 x 32 region
+    long chunks = patches > wide ? patches : wide;                      // (`wide` is also conv_patch_kernel's count: 4 per 8 x 16 tile)
+    chunks = chunks > tall ? chunks : tall;
+    chunks = chunks > w4 ? chunks : w4;
     return (long)B * chunks * C * 2 + 1024;
 }
 
