@@ -123,6 +123,8 @@ long wino_weight_floats(int rows, int cin_pad);
 // the same for F(4x4,3x3) (conv_wino4_kernel's [n-block][chunk][36 pos][32 n][8 k] layout)
 hipError_t launch_wino4_weights(const float* w, float* u, int rows, int cin_pad, hipStream_t s);
 long wino4_weight_floats(int rows, int cin_pad);
+// conv_wino_sk.hip, reached through launch_conv (tiles 44 / 45): conv_wino_kernel with the channel chunks split over sk = 2 / 4 wave groups
+hipError_t launch_wino_sk(const ConvParams& p, int batch, hipStream_t s, int sk);
 // conv_patch.hip, reached through launch_conv (tile 43): planar small-Cin inputs (A_GATHER) with an LDS-resident input patch
 bool patch_ok(const ConvParams& p);
 int patch_tiles(int Ho, int Wo);

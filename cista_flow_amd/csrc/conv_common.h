@@ -559,6 +559,20 @@ static inline bool dma_range_ok(const ConvParams& p) {
 }
 
 
+// ---- Winograd F(2x2,3x3) geometry shared by conv_wino_kernel (conv_igemm.hip) and its split-K form (conv_wino_sk.hip) ----
+// tiles per region: 4 x 8 (8 x 16 output pixels, "wide") or 8 x 4 (16 x 8, "tall"), whichever wastes fewer pixels on the
+// image's ragged edge (90 x 120: 96 x 128 = +13.8 % wide, 96 x 120 = +6.7 % tall); the patch is 10 x 18 or 18 x 10 pixels
+static constexpr int WG_PIX = 180;
+__host__ __device__ inline int wino_tall(int Ho, int Wo) {
+    const long wide = (long)((Ho + 7) / 8 * 8) * ((Wo + 15) / 16 * 16), tall = (long)((Ho + 15) / 16 * 16) * ((Wo + 7) / 8 * 8);
+    return tall < wide ? 1 : 0;
+}
+static constexpr int WG_KC = 8;                             // channels per chunk
+static constexpr int WG_PLANE = 192;                        // cells per channel-quad plane of a raw buffer (180 live)
+static constexpr int WG_RAW = 512 * 4;                      // floats per raw buffer: two planes of 16-byte slots, padded to 2 x 256 slots
+static constexpr int WG_UV = 16 * 32 * WG_KC;               // floats of a chunk's U block (4096)
+
+
 #ifdef CF_CENSUS
 // residency census (tools/census_probe.py): wave 0 of every workgroup records where and when it ran --
 // [HW_ID, XCC_ID, start, end] (100 MHz real-time counter) -- so that the number of workgroups a CU really holds at once can be counted

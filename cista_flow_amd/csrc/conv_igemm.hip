@@ -903,16 +903,6 @@ void conv_dma_kernel(const ConvParams p) {
 // ---------------------------------------------------------------------------------------------------------
 // tiles per region: 4 x 8 (8 x 16 output pixels, "wide") or 8 x 4 (16 x 8, "tall"), whichever wastes fewer pixels on the
 // image's ragged edge (90 x 120: 96 x 128 = +13.8 % wide, 96 x 120 = +6.7 % tall); the patch is 10 x 18 or 18 x 10 pixels
-static constexpr int WG_PIX = 180;
-__host__ __device__ inline int wino_tall(int Ho, int Wo) {
-    const long wide = (long)((Ho + 7) / 8 * 8) * ((Wo + 15) / 16 * 16), tall = (long)((Ho + 15) / 16 * 16) * ((Wo + 7) / 8 * 8);
-    return tall < wide ? 1 : 0;
-}
-static constexpr int WG_KC = 8;                             // channels per chunk
-static constexpr int WG_PLANE = 192;                        // cells per channel-quad plane of a raw buffer (180 live)
-static constexpr int WG_RAW = 512 * 4;                      // floats per raw buffer: two planes of 16-byte slots, padded to 2 x 256 slots
-static constexpr int WG_UV = 16 * 32 * WG_KC;               // floats of a chunk's U block (4096)
-
 #ifndef WG_ABL
 #define WG_ABL 0
 #endif
@@ -1434,7 +1424,7 @@ static int wino_regions(int Ho, int Wo) {
 
 // statistics partials a convolution with st_partial writes per image: one per 32-pixel patch, or per Winograd tile row
 int conv_stats_chunks(const ConvParams& p, int tile) {
-    if (tile == 40 || tile == 41) return wino_regions(p.Ho, p.Wo) * 4;
+    if (tile == 40 || tile == 41 || tile == 44 || tile == 45) return wino_regions(p.Ho, p.Wo) * 4;
     if (tile == 42) return wino4_regions(p.Ho, p.Wo) * 16;
     if (tile == 43) return patch_tiles(p.Ho, p.Wo) * 4;
     return (p.Ho * p.Wo + 31) / 32;
@@ -1724,6 +1714,8 @@ const char* conv_tile_name(int tile) {
         case 41: return "conv_wino8_kernel";
         case 42: return "conv_wino4_kernel";
         case 43: return "conv_patch_kernel";
+        case 44: return "conv_wino_sk_kernel<2>";
+        case 45: return "conv_wino_sk_kernel<4>";
         default: return "?";
     }
 }
@@ -1826,6 +1818,18 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
         const long wg = (long)wino_regions(p.Ho, p.Wo) * ((p.cout + 31) / 32) * tb;
         static const long wmin = getenv("CF_WINO_MIN") ? atol(getenv("CF_WINO_MIN")) : 128;
         if (wg >= wmin) tile = 40;      // (the eight-wave tile 41 measured -3..+6 % per layer, -1.4 % on the whole step: explicit only)
+        // CF_WINO_SK=1 (opt-in): under-filled launches split the chunks over 2 or 4 wave groups per workgroup (conv_wino_sk.hip).  Off by
+        // default: no gain in the model (1417-1428 frames/s with and without on one box)
+        static const int sk_on = getenv("CF_WINO_SK") ? atoi(getenv("CF_WINO_SK")) : 0;
+        // measured (tools/conv_bench.py, 1/8-resolution layers at B = 8): the split pays only while the workgroups still fit ONE round of
+        // their larger footprint -- 192 workgroups (menc.conv, encoder stage 3): 36.7 -> 31.5 us / 18.1 -> 16.4 us with two groups, the same with
+        // four; 288 (convc2), 384 (fh.conv1), 576 (stage 2): equal or slower (a second round of 64 KB / 128 KB workgroups)
+        static const long sk4_max = getenv("CF_WINO_SK4_MAX") ? atol(getenv("CF_WINO_SK4_MAX")) : 0;
+        static const long sk2_max = getenv("CF_WINO_SK2_MAX") ? atol(getenv("CF_WINO_SK2_MAX")) : 256;
+        if (tile == 40 && sk_on && p.prec == 0 && p.cin_pad >= 64) {
+            if (wg <= sk4_max) tile = 45;
+            else if (wg <= sk2_max) tile = 44;
+        }
     }
     // F(4x4,3x3) (tile 42): 1.78x fewer MFMAs again, in workgroups of 512 output pixels x 32 channels -- taken when the launch
     // still has enough of them to fill the chip (CF_WINO4_MIN workgroups; 0 = never)
@@ -1886,7 +1890,7 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
                 tile = wgs128x128 >= 2304 ? 25 : ((p.cout >= 256 && p.cout % 128 == 0) ? 28 : 23);
         }
     }
-    if (tile >= 20 && tile <= 42 && !(p.a_mode == A_NHWC && dma_range_ok(p))) return hipErrorInvalidValue;
+    if (((tile >= 20 && tile <= 42) || tile == 44 || tile == 45) && !(p.a_mode == A_NHWC && dma_range_ok(p))) return hipErrorInvalidValue;
     if (tile == 43 && !patch_ok(p)) return hipErrorInvalidValue;   // explicit DMA tile, image too large
     if (tile_used) *tile_used = tile;
     g_last_launch.kernel = conv_tile_name(tile);
@@ -1932,6 +1936,8 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
         case 41: return launch_wino8(p, batch, s);
         case 42: return launch_wino4(p, batch, s);
         case 43: return launch_patch(p, batch, s);
+        case 44: return wino_ok(p) ? launch_wino_sk(p, batch, s, 2) : hipErrorInvalidValue;
+        case 45: return wino_ok(p) ? launch_wino_sk(p, batch, s, 4) : hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }
 }

@@ -143,6 +143,8 @@ STATS_CASES = [
     (64, 128, 3, 3, 1, 1, 0, 41, 21, 37),    # eight-wave Winograd tile
     (1, 64, 7, 7, 2, 3, 2, 43, 37, 53),      # patch kernel (planar small-Cin input), ragged tiles
     (5, 64, 7, 7, 2, 3, 2, 43, 64, 80),
+    (96, 96, 3, 3, 1, 1, 0, 44, 21, 37),     # split-K Winograd (2 / 4 wave groups)
+    (128, 128, 3, 3, 1, 1, 0, 45, 24, 32),
     (64, 64, 3, 3, 1, 1, 0, 42, 48, 64),     # F(4x4,3x3): sixteen partials per 32-tile region
     (96, 96, 3, 3, 1, 1, 0, 42, 21, 37),     # ... ragged regions
     (64, 160, 3, 3, 1, 1, 0, 42, 17, 17),    # ... a small ragged map with B * Cout > 128 (partial-buffer sizing)
@@ -220,6 +222,11 @@ def test_conv_winograd(gpu, case):
     assert got.shape == ref.shape
     assert (got - ref).abs().max().item() < 1e-4
     assert (got - direct).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    for sk_tile in (44, 45):                   # chunks split over 2 / 4 wave groups of a workgroup (odd chunk counts: dead steps)
+        gsk = run_conv(gpu, x, w, b, 1, 1, 1, pad_mode, 0, epi, sk_tile, H, W)
+        assert (gsk - ref).abs().max().item() < 1e-4, sk_tile
+        assert (gsk - got).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), sk_tile
+        assert torch.equal(gsk, run_conv(gpu, x, w, b, 1, 1, 1, pad_mode, 0, epi, sk_tile, H, W))
     if Cout % 64 == 0 and Cin % 16 == 0:       # the eight-wave kernel (tile 41): 64 output channels x 16-channel chunks
         got8 = run_conv(gpu, x, w, b, 1, 1, 1, pad_mode, 0, epi, 41, H, W)
         assert (got8 - ref).abs().max().item() < 1e-4
