@@ -70,7 +70,10 @@ size_t cf_workspace_bytes(const cf_handle* h);
 /* weights: announce every state_dict entry (name = reference state_dict key, fp32, contiguous,
  * PyTorch layout e.g. OIHW), then cf_finalize_weights packs them on `stream` (BatchNorm folded,
  * K-contiguous [cout][tap][cin] matrices).  The announced pointers are only read during
- * cf_finalize_weights.  Replaces nn.Module.load_state_dict + .to(device) for the hot path. */
+ * cf_finalize_weights.  Replaces nn.Module.load_state_dict + .to(device) for the hot path.
+ * cf_finalize_weights is the ONE entry point that synchronises: it ends with hipStreamSynchronize(stream), because the announced
+ * pointers may die as soon as it returns (the packing kernels must have read them).  It runs once per weight change, never per
+ * frame; every forward entry point below is asynchronous on its stream. */
 int cf_load_weights(cf_handle* h, const char* name, const void* dev_ptr, const int64_t* shape, int ndim);
 int cf_finalize_weights(cf_handle* h, void* stream);
 
