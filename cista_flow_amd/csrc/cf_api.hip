@@ -134,6 +134,7 @@ struct cf_handle {
     int last_tile = 0;             // tile kind of the last run_conv launch (statistics chunk count of the Winograd tile)
     bool enc_pair = false;         // CF_ENC_PAIR=1: fnet + enet as one 2B batch instead of two streams
     bool wino = true;              // CF_WINO=0: 3x3 convolutions on the direct implicit-GEMM kernel instead of Winograd F(2x2,3x3)
+    bool wino1d = true;            // CF_WINO1D=0: no one-dimensional F(2,5) weights / kernel for the 1x5 / 5x1 layers (conv_wino1d_kernel)
     bool wino4 = true;             // CF_WINO4=0: no F(4x4,3x3) weights / kernel (conv_wino4_kernel)
     // CF_PHASES=1 (tuning aid): HIP events on the caller's stream at the phase boundaries of cf_step, averaged
     // and printed to stderr by cf_destroy
@@ -476,7 +477,7 @@ ConvParams nhwc_conv(const PackedConv& pc, std::initializer_list<Seg> segs, int 
         p.w_bs = (long)pc.rows * pc.Ktot;
         p.bias_gs = pc.rows;
         p.w_div = -pc.groups;
-        p.wino_gs = pc.wino ? wino_weight_floats(pc.cout, pc.cin_pad) : 0;
+        p.wino_gs = !pc.wino ? 0 : (pc.KH == 3 ? wino_weight_floats(pc.cout, pc.cin_pad) : wino1d_weight_floats(pc.cout, pc.cin_pad));
         p.wino4_gs = pc.wino4 ? wino4_weight_floats(pc.cout, pc.cin_pad) : 0;
     }
     p.out = out; p.out_ld = out_ld; p.out_bs = out_bs; p.cout = pc.cout; p.epi = epi;
@@ -777,7 +778,17 @@ extern "C" int cf_finalize_weights(cf_handle* h, void* stream) {
         // PACKED matrix so that BatchNorm folds, row stacking / interleaving and channel slices carry over
         for (auto& kv : h->conv) {
             PackedConv& pc = kv.second;
-            if (!pc.w || pc.gather || pc.KH != 3 || pc.KW != 3) continue;
+            if (!pc.w || pc.gather) continue;
+            if (h->cfg.precision == 0 && h->wino1d && ((pc.KH == 1 && pc.KW == 5) || (pc.KH == 5 && pc.KW == 1)) && pc.cin_pad % 16 == 0) {
+                // the separable GRU's 1x5 / 5x1 matrices: U = G g of the one-dimensional F(2,5) (6/5 of the packed matrix; conv_wino1d.hip)
+                const size_t wf1 = (size_t)wino1d_weight_floats(pc.cout, pc.cin_pad);
+                CF_HIP(h, hipMalloc(reinterpret_cast<void**>(&pc.wino), sizeof(float) * wf1 * pc.groups));
+                h->owned.push_back(pc.wino);
+                for (int g = 0; g < pc.groups; ++g)
+                    CF_HIP(h, launch_wino1d_weights(pc.w + (size_t)g * pc.rows * pc.Ktot, pc.wino + g * wf1, pc.cout, pc.cin_pad, st));
+                continue;
+            }
+            if (pc.KH != 3 || pc.KW != 3) continue;
             const size_t wf = (size_t)wino_weight_floats(pc.cout, pc.cin_pad);
             CF_HIP(h, hipMalloc(reinterpret_cast<void**>(&pc.wino), sizeof(float) * wf * pc.groups));
             h->owned.push_back(pc.wino);
@@ -853,6 +864,7 @@ extern "C" int cf_create(cf_handle** out, const cf_config* cfg) {
     if (const char* e = getenv("CF_ENC_PAIR")) h->enc_pair = atoi(e) != 0;      // before the arena is laid out
     if (const char* e = getenv("CF_WINO")) h->wino = atoi(e) != 0;
     if (const char* e = getenv("CF_WINO4")) h->wino4 = atoi(e) != 0;
+    if (const char* e = getenv("CF_WINO1D")) h->wino1d = atoi(e) != 0;
     g_wino4_min = getenv("CF_WINO4_MIN") ? atol(getenv("CF_WINO4_MIN")) : 0;
     if (const char* e = getenv("CF_ARENA_SKEW")) h->arena.skew = (size_t)atol(e) & ~size_t(255);
     if (const char* e = getenv("CF_ARENA_ALIGN")) {
@@ -1932,6 +1944,11 @@ static int op_conv2d_impl(const float* in, int B, int Cin, int H, int W, const f
     if ((tile == 40 || tile == 41 || tile == 44 || tile == 45) && !gather && KH == 3 && KW == 3) {      // Winograd tile: needs the transformed weights
         if (hipMalloc(&wino.p, sizeof(float) * (size_t)wino_weight_floats(Cout, pc.cin_pad)) != hipSuccess) return CF_ERR_HIP;
         if (launch_wino_weights(pc.w, static_cast<float*>(wino.p), Cout, pc.cin_pad, st) != hipSuccess) return CF_ERR_HIP;
+        p.w_wino = static_cast<float*>(wino.p);
+    }
+    if (tile == 46 && !gather && ((KH == 1 && KW == 5) || (KH == 5 && KW == 1))) {      // one-dimensional Winograd F(2,5)
+        if (hipMalloc(&wino.p, sizeof(float) * (size_t)wino1d_weight_floats(Cout, pc.cin_pad)) != hipSuccess) return CF_ERR_HIP;
+        if (launch_wino1d_weights(pc.w, static_cast<float*>(wino.p), Cout, pc.cin_pad, st) != hipSuccess) return CF_ERR_HIP;
         p.w_wino = static_cast<float*>(wino.p);
     }
     TmpBuf part;

@@ -74,7 +74,7 @@ struct ConvParams {
     float g_scale, g_shift;
     // ---- B operand (packed weights [w_rows][Ktot], K contiguous) ----
     const float* w;
-    const float* w_wino; // Winograd F(2x2,3x3) transform of w (launch_wino_weights; nullable): enables tile 40
+    const float* w_wino; // Winograd transform of w (nullable): F(2x2,3x3) of a 3x3 matrix (launch_wino_weights, tile 40) or F(2,5) of a 1x5 / 5x1 one (launch_wino1d_weights, tile 46)
     long wino_gs;       // floats between the Winograd matrices of consecutive weight groups (w_div)
     const float* w_wino4; // Winograd F(4x4,3x3) transform of w (launch_wino4_weights; nullable): enables tile 42
     long wino4_gs;
@@ -125,6 +125,13 @@ hipError_t launch_wino4_weights(const float* w, float* u, int rows, int cin_pad,
 long wino4_weight_floats(int rows, int cin_pad);
 // conv_wino_sk.hip, reached through launch_conv (tiles 44 / 45): conv_wino_kernel with the channel chunks split over sk = 2 / 4 wave groups
 hipError_t launch_wino_sk(const ConvParams& p, int batch, hipStream_t s, int sk);
+// conv_wino1d.hip, reached through launch_conv (tile 46): one-dimensional Winograd F(2,5) for 1x5 / 5x1 convolutions (the separable GRU);
+// its transformed weights travel in w_wino / wino_gs (a 1x5 / 5x1 layer has no F(2x2,3x3) form, so the field is free)
+hipError_t launch_wino1d_weights(const float* w, float* u, int rows, int cin_pad, hipStream_t s);
+long wino1d_weight_floats(int rows, int cin_pad);
+bool wino1d_ok(const ConvParams& p);
+long wino1d_workgroups(const ConvParams& p, long batch);
+hipError_t launch_wino1d(const ConvParams& p, int batch, hipStream_t s);
 // conv_patch.hip, reached through launch_conv (tile 43): planar small-Cin inputs (A_GATHER) with an LDS-resident input patch
 bool patch_ok(const ConvParams& p);
 int patch_tiles(int Ho, int Wo);

@@ -1713,6 +1713,7 @@ const char* conv_tile_name(int tile) {
         case 40: return "conv_wino_kernel";
         case 41: return "conv_wino8_kernel";
         case 42: return "conv_wino4_kernel";
+        case 46: return "conv_wino1d_kernel";
         case 43: return "conv_patch_kernel";
         case 44: return "conv_wino_sk_kernel<2>";
         case 45: return "conv_wino_sk_kernel<4>";
@@ -1831,6 +1832,12 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
             else if (wg <= sk2_max) tile = 44;
         }
     }
+    // 1x5 / 5x1 layers with transformed weights (the separable GRU): one-dimensional Winograd F(2,5), 1.67x fewer MFMAs (conv_wino1d.hip)
+    if (tile == 0 && wino1d_ok(p)) {
+        const long tb = p.tile_batch > 0 ? p.tile_batch : batch;
+        static const long w1min = getenv("CF_WINO1D_MIN") ? atol(getenv("CF_WINO1D_MIN")) : 128;
+        if (wino1d_workgroups(p, tb) >= w1min) tile = 46;
+    }
     // F(4x4,3x3) (tile 42): 1.78x fewer MFMAs again, in workgroups of 512 output pixels x 32 channels -- taken when the launch
     // still has enough of them to fill the chip (CF_WINO4_MIN workgroups; 0 = never)
     if ((tile == 0 || (auto_tile && tile == 40)) && wino4_ok(p)) {
@@ -1936,6 +1943,7 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
         case 41: return launch_wino8(p, batch, s);
         case 42: return launch_wino4(p, batch, s);
         case 43: return launch_patch(p, batch, s);
+        case 46: return launch_wino1d(p, batch, s);
         case 44: return wino_ok(p) ? launch_wino_sk(p, batch, s, 2) : hipErrorInvalidValue;
         case 45: return wino_ok(p) ? launch_wino_sk(p, batch, s, 4) : hipErrorInvalidValue;
         default: return hipErrorInvalidValue;

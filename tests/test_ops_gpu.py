@@ -260,6 +260,39 @@ def test_conv_winograd_f4x4(gpu, case):
     assert torch.equal(got, run_conv(gpu, x, w, b, 1, 1, 1, pad_mode, 0, epi, 42, H, W))     # deterministic
 
 
+WINO1D_CASES = [
+    # Cin, Cout, horizontal, H, W, pad_mode, epi
+    (256, 256, True, 23, 30, 0, 0), (256, 128, False, 23, 30, 0, 0), (64, 96, True, 9, 13, 0, 3), (64, 96, False, 9, 13, 0, 2),
+    (16, 40, True, 5, 7, 0, 0), (16, 40, False, 7, 5, 0, 1), (128, 32, True, 60, 80, 1, 0), (128, 32, False, 60, 80, 1, 0),
+    (48, 64, True, 1, 4, 0, 0), (48, 64, False, 4, 1, 0, 0), (32, 32, True, 3, 65, 0, 0),
+]
+
+
+@pytest.mark.parametrize("case", WINO1D_CASES)
+def test_conv_winograd_1d(gpu, case):
+    """conv_wino1d_kernel (tile 46): one-dimensional Winograd F(2,5) for the separable GRU's 1x5 / 5x1 convolutions -- odd and even line
+    lengths, lines shorter than a window, tile groups that straddle lines and end ragged, zero and reflect padding, partial
+    output-channel blocks, fused activations -- against an fp64 convolution and the direct kernel; bit-reproducible."""
+    Cin, Cout, horiz, H, W, pad_mode, epi = case
+    g = torch.Generator().manual_seed(4600 + Cin + Cout + H + W)
+    B = 3
+    KH, KW, pT, pL = (1, 5, 0, 2) if horiz else (5, 1, 2, 0)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, KH, KW, generator=g) / (Cin * 5) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref64 = ref_conv(x.double(), w.double(), b.double(), 1, pT, pL, pad_mode)
+    act = {0: lambda t: t, 1: torch.relu, 2: torch.sigmoid, 3: torch.tanh}[epi]
+    scale = max(1.0, ref64.abs().max().item())
+    ref = act(ref64).float()
+    got = run_conv(gpu, x, w, b, 1, pT, pL, pad_mode, 0, epi, 46, H, W)
+    assert got.shape == ref.shape
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() < 1e-5 * scale, (got - ref).abs().max().item()
+    direct = run_conv(gpu, x, w, b, 1, pT, pL, pad_mode, 0, epi, 4, H, W)       # conv_igemm_kernel<64,64>
+    assert (got - direct).abs().max().item() < 1e-5 * scale
+    assert torch.equal(got, run_conv(gpu, x, w, b, 1, pT, pL, pad_mode, 0, epi, 46, H, W))     # deterministic
+
+
 @pytest.mark.parametrize("epi", [1, 2, 3])
 def test_conv_epilogue_activation(gpu, epi):
     g = torch.Generator().manual_seed(7 + epi)

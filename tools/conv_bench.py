@@ -19,6 +19,11 @@ dev = torch.device("cuda:0")
 SHAPES = [
     ("gru.zr    384->256 1x5 @24x32", 8, 384, 24, 32, 256, 1, 5, 1, 0, 2, 0),
     ("gru.q     384->128 1x5 @24x32", 8, 384, 24, 32, 128, 1, 5, 1, 0, 2, 0),
+    # the per-iteration GRU convolutions as the model runs them (the context third of K is precomputed once per step: gru.pre)
+    ("zr.h      256->256 1x5 @23x30", 8, 256, 23, 30, 256, 1, 5, 1, 0, 2, 0),
+    ("q.h       256->128 1x5 @23x30", 8, 256, 23, 30, 128, 1, 5, 1, 0, 2, 0),
+    ("zr.v      256->256 5x1 @23x30", 8, 256, 23, 30, 256, 5, 1, 1, 2, 0, 0),
+    ("q.v       256->128 5x1 @23x30", 8, 256, 23, 30, 128, 5, 1, 1, 2, 0, 0),
     ("convc2    256->192 3x3 @24x32", 8, 256, 24, 32, 192, 3, 3, 1, 1, 1, 0),
     ("menc      320->128 3x3 @24x32", 8, 320, 24, 32, 128, 3, 3, 1, 1, 1, 0),
     ("fh.conv1  128->256 3x3 @24x32", 8, 128, 24, 32, 256, 3, 3, 1, 1, 1, 0),
