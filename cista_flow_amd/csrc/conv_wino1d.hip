@@ -35,6 +35,11 @@ __global__ __launch_bounds__(256, 4) void conv_wino1d_kernel(const ConvParams p)
     __shared__ __attribute__((aligned(16))) float smem[8 * W1_P + 64];   // ONE __shared__ object (see conv_wino_kernel): 37,120 bytes
     float* const sRaw = smem;
     int* const sMtab = reinterpret_cast<int*>(smem + 8 * W1_P);
+#ifdef CF_STAMP
+    const long long t_begin = __builtin_readcyclecounter();
+    const long long r_begin = (long long)__builtin_amdgcn_s_memrealtime();
+    long long st_wait = 0;
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -120,8 +125,14 @@ __global__ __launch_bounds__(256, 4) void conv_wino1d_kernel(const ConvParams p)
     f32x4 bu[3];
     auto chunk_step = [&](int k) __attribute__((always_inline)) {
         // in flight, oldest first: the three raw(k) pieces, then the three U(k) loads
+#ifdef CF_STAMP
+        const long long t0 = __builtin_readcyclecounter();
+#endif
         asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         raw_barrier();                              // raw(k) has landed for everybody; everybody has read raw(k-1)
+#ifdef CF_STAMP
+        st_wait += __builtin_readcyclecounter() - t0;
+#endif
         const bool more = k + 1 < nchunk;
         issue_raw(((k + 1) & 1) * W1_RAW, more);
         __builtin_amdgcn_sched_barrier(0);          // raw(k+1) before U(k+1) in issue order: the vmcnt(3) above counts on it
@@ -169,7 +180,13 @@ __global__ __launch_bounds__(256, 4) void conv_wino1d_kernel(const ConvParams p)
     for (int j = 0; j < 3; ++j) bu[j] = buf_load4(u_rsrc, uoff + 2048u * j, 0);
     __builtin_amdgcn_sched_barrier(0);
     // (requesting raw and U TWO chunks ahead -- ring of three, two sets of U registers -- measured no faster: 34.8 vs 34.1 us)
+#ifdef CF_STAMP
+    const long long t_loop_begin = __builtin_readcyclecounter();
+#endif
     for (int k = 0; k < nchunk; ++k) chunk_step(k);
+#ifdef CF_STAMP
+    const long long t_loop_end = __builtin_readcyclecounter();
+#endif
 
     __syncthreads();                                // every wave is done with the raw ring before the patches go on top of it
     // ---- this wave's columns of A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 1]: two partial patches [tile][cout], row stride EPI_S ----
@@ -196,6 +213,15 @@ __global__ __launch_bounds__(256, 4) void conv_wino1d_kernel(const ConvParams p)
     // wave w finishes rows [16 (w >> 1), + 16) of patch j' = w & 1: the sum of the four waves' partials, in wave order
     const int jp = wave & 1, q0 = (wave >> 1) * 2;
     patch_tail(p, smem + jp * W1_P, b, 0, n0, lane, p.Ho * p.Wo, q0, q0 + 2, 4, 2 * W1_P, sMtab + jp * 32);
+#ifdef CF_STAMP
+    if (p.stamp && lane == 0) {      // [DMA wait + barrier, -, -, prologue, chunks, loop, tail, MHz] cycles of this wave
+        long long* q = p.stamp + ((long)blockIdx.x * 4 + wave) * 8;
+        q[0] = st_wait; q[1] = 0; q[2] = 0; q[3] = t_loop_begin - t_begin; q[4] = nchunk;
+        q[5] = t_loop_end - t_loop_begin; q[6] = __builtin_readcyclecounter() - t_loop_end;
+        const long long dr = (long long)__builtin_amdgcn_s_memrealtime() - r_begin;
+        q[7] = dr > 0 ? ((__builtin_readcyclecounter() - t_begin) * 100) / dr : 0;
+    }
+#endif
 }
 
 // U = G g of a packed direct matrix w [rows][5 taps][cin_pad], stored [n-block][chunk][pos 6][32 n][16 k]; rows past `rows` are zero
