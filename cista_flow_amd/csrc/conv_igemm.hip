@@ -1819,9 +1819,10 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
         const long wg = (long)wino_regions(p.Ho, p.Wo) * ((p.cout + 31) / 32) * tb;
         static const long wmin = getenv("CF_WINO_MIN") ? atol(getenv("CF_WINO_MIN")) : 128;
         if (wg >= wmin) tile = 40;      // (the eight-wave tile 41 measured -3..+6 % per layer, -1.4 % on the whole step: explicit only)
-        // CF_WINO_SK=1 (opt-in): under-filled launches split the chunks over 2 or 4 wave groups per workgroup (conv_wino_sk.hip).  Off by
-        // default: no gain in the model (1417-1428 frames/s with and without on one box)
-        static const int sk_on = getenv("CF_WINO_SK") ? atoi(getenv("CF_WINO_SK")) : 0;
+        // Launches of at most CF_WINO_SK2_MAX workgroups (every CU gets ONE or none) split the chunks over 2 wave groups per workgroup
+        // (conv_wino_sk.hip): +0.4 % on the step in three alternating A/B pairs on one box (1564 -> 1570 frames/s; menc.conv, encoder
+        // stage 3).  CF_WINO_SK=0 turns it off.
+        static const int sk_on = getenv("CF_WINO_SK") ? atoi(getenv("CF_WINO_SK")) : 1;
         // measured (tools/conv_bench.py, 1/8-resolution layers at B = 8): the split pays only while the workgroups still fit ONE round of
         // their larger footprint -- 192 workgroups (menc.conv, encoder stage 3): 36.7 -> 31.5 us / 18.1 -> 16.4 us with two groups, the same with
         // four; 288 (convc2), 384 (fh.conv1), 576 (stage 2): equal or slower (a second round of 64 KB / 128 KB workgroups)

@@ -1,12 +1,13 @@
 // conv_wino_sk.hip -- conv_wino_kernel (Winograd F(2x2,3x3), conv_igemm.hip) with the channel chunks SPLIT over SK wave groups of
 // one workgroup (round 3).  Launched through launch_conv (conv_igemm.hip) as tile 44 (SK = 2) / 45 (SK = 4).  gfx950 only.
 //
-// STATUS: parity-green (test_conv_winograd, tiles 44 / 45; test_conv_fused_inorm_stats) and OPT-IN (CF_WINO_SK=1).  The hypothesis below
-// was half right: with 190-290 workgroups the launch is not bound by one workgroup's serial chain but by the matrix-pipe time of the ONE
-// workgroup a CU gets (convc2: 288 workgroups x 131 k pipe cycles on 256 CUs = two rounds of 16 us at best, whatever happens inside the
-// workgroup) -- the split overlaps the exposed per-chunk overhead (menc.conv 36.7 -> 31.5 us, encoder stage 3 18.1 -> 16.4 us in isolation)
-// but cannot spread the work over more CUs, and in the model the step does not move.  What these layers need is MORE, smaller workgroups
-// (16 tiles or 16 output channels each) -- or a bigger batch.
+// STATUS: parity-green (test_conv_winograd, tiles 44 / 45; test_conv_fused_inorm_stats); SK = 2 is what launch_conv takes for Winograd
+// launches of at most 256 workgroups (CF_WINO_SK2_MAX; CF_WINO_SK=0 turns it off): +0.4 % on the 180x240 B=8 step in three alternating
+// A/B pairs (+0.5 % at B=4, neutral at B=1).  The hypothesis below was half right: with 190-290 workgroups the launch is not bound by one
+// workgroup's serial chain but by the matrix-pipe time of the ONE workgroup a CU gets (convc2: 288 workgroups x 131 k pipe cycles on 256
+// CUs = two rounds of 16 us at best, whatever happens inside the workgroup) -- the split overlaps the exposed per-chunk overhead (menc.conv
+// 36.7 -> 31.5 us, encoder stage 3 18.1 -> 16.4 us in isolation) but cannot spread the work over more CUs.  What the layers above 256
+// workgroups need is MORE, smaller workgroups (16 tiles or 16 output channels each) -- or a bigger batch.
 //
 // Why: the 3x3 layers at 1/8 resolution (convc2, the motion encoder's conv, FlowHead.conv1 -- 18 launches per step -- fusion.convo,
 // encoder stage 3) and stage 2 of the encoders are launches of 190-580 workgroups on a chip with 1024 slots.  Every workgroup then has
