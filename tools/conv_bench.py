@@ -24,6 +24,11 @@ SHAPES = [
     ("q.h       256->128 1x5 @23x30", 8, 256, 23, 30, 128, 1, 5, 1, 0, 2, 0),
     ("zr.v      256->256 5x1 @23x30", 8, 256, 23, 30, 256, 5, 1, 1, 2, 0, 0),
     ("q.v       256->128 5x1 @23x30", 8, 256, 23, 30, 128, 5, 1, 1, 2, 0, 0),
+    ("convc1    336->256 1x1 @23x30", 8, 336, 23, 30, 256, 1, 1, 1, 0, 0, 0),
+    ("convf2    128->64  3x3 @23x30", 8, 128, 23, 30, 64, 3, 3, 1, 1, 1, 0),
+    ("l2.0.c1    64->96  3x3/2 @90x120", 8, 64, 90, 120, 96, 3, 3, 2, 1, 1, 0),
+    ("l3.0.c1    96->128 3x3/2 @45x60", 8, 96, 45, 60, 128, 3, 3, 2, 1, 1, 0),
+    ("l2.ds      64->96  1x1/2 @90x120", 8, 64, 90, 120, 96, 1, 1, 2, 0, 0, 0),
     ("convc2    256->192 3x3 @24x32", 8, 256, 24, 32, 192, 3, 3, 1, 1, 1, 0),
     ("menc      320->128 3x3 @24x32", 8, 320, 24, 32, 128, 3, 3, 1, 1, 1, 0),
     ("fh.conv1  128->256 3x3 @24x32", 8, 128, 24, 32, 256, 3, 3, 1, 1, 1, 0),
