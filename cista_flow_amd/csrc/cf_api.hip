@@ -1429,6 +1429,7 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
         CF_HIP(h, run_conv(h, o, B, st));
     }
     // all-pairs correlation + pyramid   raft_corr.py:22-30,56-65
+    bool fused_init = false;
     {
         ConvParams p = base_params();
         p.in[0] = h->fmap1; p.seg_c[0] = 256; p.seg_ld[0] = 256; p.seg_bs[0] = N * 256; p.nseg = 1;
@@ -1440,12 +1441,23 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
         p.k_real = 256;
         p.tag = "corr.allpairs";
         CF_HIP(h, run_conv(h, p, B, st));
-        for (int l = 1; l < 4; ++l)
-            { PROF(h, st, "corr.pool", 5.0 * B * N * h->clh[l - 1] * h->clw[l - 1]); CF_HIP(h, launch_corr_pool(h->corr[l - 1], h->corr[l], (long)B * N, h->clh[l - 1], h->clw[l - 1], st)); }
+        // pyramid levels 1..3, coords1 = grid (+ flow_init) and the frame's "any flow" flag in ONE launch where the level-0 map fits
+        // the kernel's LDS staging (three pool launches + coords_init + a memset node otherwise: five ~6 us launches on the critical path)
+        const int fuse_env = getenv("CF_PYRAMID_FUSED") ? atoi(getenv("CF_PYRAMID_FUSED")) : 1;      // read per call: tests flip it
+        fused_init = fuse_env && h->clh[3] >= 1 && h->clw[3] >= 1 && corr_pyramid_lds_bytes(h->clh[0], h->clw[0]) <= 64 * 1024;
+        if (fused_init) {
+            PROF(h, st, "corr.pyramid", 4.0 * B * N * (h->clh[0] * h->clw[0] + h->clh[1] * h->clw[1] + h->clh[2] * h->clw[2] + h->clh[3] * h->clw[3]) + 8.0 * B * N * (flow_init ? 2 : 1));
+            CF_HIP(h, launch_corr_pyramid(h->corr[0], h->corr[1], h->corr[2], h->corr[3], (long)B * N, h->clh[0], h->clw[0], h->coords1, flow_init, B, h8, w8, flag, st));
+        } else {
+            for (int l = 1; l < 4; ++l)
+                { PROF(h, st, "corr.pool", 5.0 * B * N * h->clh[l - 1] * h->clw[l - 1]); CF_HIP(h, launch_corr_pool(h->corr[l - 1], h->corr[l], (long)B * N, h->clh[l - 1], h->clw[l - 1], st)); }
+        }
     }
     h->phase_mark(1, st);
-    { PROF(h, st, "coords_init", 8.0 * B * N * (flow_init ? 2 : 1)); CF_HIP(h, launch_coords_init(h->coords1, flow_init, B, h8, w8, st)); }
-    if (flag) CF_HIP(h, hipMemsetAsync(flag, 0, sizeof(int), st));
+    if (!fused_init) {
+        { PROF(h, st, "coords_init", 8.0 * B * N * (flow_init ? 2 : 1)); CF_HIP(h, launch_coords_init(h->coords1, flow_init, B, h8, w8, st)); }
+        if (flag) CF_HIP(h, hipMemsetAsync(flag, 0, sizeof(int), st));
+    }
     const int iters = h->cfg.iters;
     // The up-sampled flow of the intermediate iterations (flow_preds) is nobody's input: it is produced on side stream
     // 1 while the next iteration runs.  It reads net / coords1, which the next iteration updates in place, so the main

@@ -211,6 +211,11 @@ struct LookupParams {
     float* coords_out;                      // = coords1 (in place: a query only reads and writes its own pixel)
 };
 hipError_t launch_corr_lookup(const LookupParams& p, hipStream_t s);
+// levels 1..3 of the correlation pyramid in one launch (bit-identical to three launch_corr_pool calls) + optionally coords1 = grid
+// (+ flow_init) and *flag = 0 in the same launch (coords1 / flag nullable); corr_pyramid_lds_bytes > 64 KiB: not available, use the cascade
+long corr_pyramid_lds_bytes(int H0, int W0);
+hipError_t launch_corr_pyramid(const float* l0, float* l1, float* l2, float* l3, long rows, int H0, int W0, float* coords1,
+                               const float* flow_init, int B, int h8, int w8, int* flag, hipStream_t s);
 
 // coords1 = grid (+ flow_init)
 hipError_t launch_coords_init(float* coords1, const float* flow_init, int B, int h8, int w8, hipStream_t s);

@@ -451,6 +451,88 @@ hipError_t launch_corr_pool(const float* src, float* dst, long rows, int Hs, int
     return hipGetLastError();
 }
 
+// The three pooled levels in ONE launch (the cascade is three ~6.5 us launches of almost no work on the step's critical path): a wave
+// takes one (b, i) row, stages its level-0 map in LDS and pools it three times there -- every level is computed from the rounded
+// values of the level above with corr_pool_kernel's expression, so the pyramid is bit-identical to the cascade.  The trailing
+// blocks initialise coords1 (coords_init_kernel's job: one more tiny launch in front of the first lookup).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void corr_pyramid_kernel(const float* __restrict__ l0, float* __restrict__ l1, float* __restrict__ l2,
+                                                           float* __restrict__ l3, long rows, int H0, int W0, int nblk_pool,
+                                                           float* coords1, const float* flow_init, int B, int h8, int w8, int* flag) {
+    extern __shared__ float pyr_smem[];
+    if ((int)blockIdx.x >= nblk_pool) {
+        const long N = (long)h8 * w8;
+        const long total = (long)B * 2 * N;
+        const long gid = (long)(blockIdx.x - nblk_pool) * blockDim.x + threadIdx.x;
+        if (gid == 0 && flag) *flag = 0;                   // the "any flow" flag of this frame (was a memset node of its own)
+        if (gid >= total) return;
+        const int i = (int)(gid % N);
+        const int ch = (int)((gid / N) % 2);
+        float v = ch == 0 ? (float)(i % w8) : (float)(i / w8);
+        if (flow_init) v = v + flow_init[gid];
+        coords1[gid] = v;
+        return;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + wave;
+    if (r >= rows) return;                                   // no workgroup-wide barrier below
+    const int H1 = H0 / 2, W1 = W0 / 2, H2 = H1 / 2, W2 = W1 / 2, H3 = H2 / 2, W3 = W2 / 2;
+    const int n0 = H0 * W0, n1 = H1 * W1, n2 = H2 * W2, n3 = H3 * W3;
+    float* s0 = pyr_smem + wave * (n0 + n1 + n2);
+    float* s1 = s0 + n0;
+    float* s2 = s1 + n1;
+    const float* src = l0 + r * n0;
+    for (int t = lane; t < n0; t += 64) s0[t] = src[t];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int t = lane; t < n1; t += 64) {
+        const int y = t / W1, x = t - y * W1;
+        const float* q = s0 + (2 * y) * W0 + 2 * x;
+        const float v = (((q[0] + q[1]) + q[W0]) + q[W0 + 1]) / 4.f;
+        s1[t] = v;
+        l1[r * n1 + t] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int t = lane; t < n2; t += 64) {
+        const int y = t / W2, x = t - y * W2;
+        const float* q = s1 + (2 * y) * W1 + 2 * x;
+        const float v = (((q[0] + q[1]) + q[W1]) + q[W1 + 1]) / 4.f;
+        s2[t] = v;
+        l2[r * n2 + t] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int t = lane; t < n3; t += 64) {
+        const int y = t / W3, x = t - y * W3;
+        const float* q = s2 + (2 * y) * W2 + 2 * x;
+        l3[r * n3 + t] = (((q[0] + q[1]) + q[W2]) + q[W2 + 1]) / 4.f;
+    }
+}
+
+// LDS one workgroup (four rows) needs; above the limit the caller keeps the three-launch cascade
+long corr_pyramid_lds_bytes(int H0, int W0) {
+    const long n0 = (long)H0 * W0, n1 = (long)(H0 / 2) * (W0 / 2), n2 = (long)(H0 / 4) * (W0 / 4);
+    return 4 * (n0 + n1 + n2) * 4;
+}
+
+hipError_t launch_corr_pyramid(const float* l0, float* l1, float* l2, float* l3, long rows, int H0, int W0, float* coords1,
+                               const float* flow_init, int B, int h8, int w8, int* flag, hipStream_t s) {
+    if (!l0 || !l1 || !l2 || !l3 || rows <= 0 || H0 < 8 || W0 < 8) return hipErrorInvalidValue;
+    const long lds = corr_pyramid_lds_bytes(H0, W0);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    const long nb_pool = (rows + 3) / 4;
+    const long nb_init = coords1 ? ((long)B * 2 * h8 * w8 + 255) / 256 : 0;
+    if (nb_pool + nb_init >= 0x7FFFFFFFL) return hipErrorInvalidValue;
+    note_launch("corr_pyramid_kernel", dim3((unsigned)(nb_pool + nb_init)), dim3(256));
+    hipLaunchKernelGGL(corr_pyramid_kernel, dim3((unsigned)(nb_pool + nb_init)), dim3(256), (size_t)lds, s, l0, l1, l2, l3, rows, H0, W0,
+                       (int)nb_pool, coords1, flow_init, B, h8, w8, flag);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------
 // correlation lookup (a10): raft_corr.py:32-54 + sample_utils.py:38-52, with FlowHead.conv2 and `coords1 += delta`
 // of the PREVIOUS refinement iteration fused in front of it (with_event_updater.py:13-14, DCEIFlow.py:218): both are

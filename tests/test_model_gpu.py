@@ -274,6 +274,27 @@ def test_buffer_reassignment_is_picked_up(gpu):
         assert gu.rel_err(f3.cpu(), f1.cpu()) < 1e-6
 
 
+def test_fused_pyramid_launch_is_bit_identical(gpu, monkeypatch):
+    """The one-launch correlation pyramid (levels 1..3 + coords1 init + flag reset, corr_pyramid_kernel) against the cascade of
+    corr_pool launches it replaces: same bits, with and without flow_init, odd map sizes (23 x 30 -> 11 x 15 -> 5 x 7 -> 2 x 3)."""
+    H, W, B = 180, 240, 2
+    m = build_eiflow(H, W, 3, gpu)
+    evs = [wu.synth_events(B, 5, H, W, 40 + i).to(gpu) for i in range(2)]
+    outs = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("CF_PYRAMID_FUSED", fused)
+        prev, st, res = torch.zeros(B, 1, H, W, device=gpu), None, []
+        with torch.no_grad():
+            for ev in evs:
+                I, bf, st = m({"event_voxel": ev, "rec_img0": prev}, st, {})
+                prev = I
+                res += [I.clone(), bf["flow_final"].clone()]
+        outs[fused] = res
+    for a, b in zip(outs["1"], outs["0"]):
+        assert torch.equal(a, b)
+    assert outs["1"][1].abs().max() > 0
+
+
 def test_inputs_are_validated(gpu):
     m = build_eiflow(128, 128, 3, gpu)
     with pytest.raises(ValueError):
