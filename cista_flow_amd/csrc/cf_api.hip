@@ -1463,6 +1463,7 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
     // 1 while the next iteration runs.  It reads net / coords1, which the next iteration updates in place, so the main
     // stream waits for it (up_pending) right before the first such write -- by then it has long finished.
     bool up_pending = false;
+    bool low_done = false;
     // FlowHead.conv2 + `coords1 += delta_flow` (with_event_updater.py:13-14, DCEIFlow.py:218) of one iteration and the
     // correlation lookup of the next are one launch (both are per-query-pixel work on the 1/8 grid)
     const PackedConv& fh2 = h->conv["fh.conv2"];
@@ -1554,7 +1555,8 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
             if (last || up)
                 { PROF(h, su, "upflow8", 8.0 * B * (N + (up ? (double)h->Hp * h->Wp : 0.0) + (last ? (double)h->H * h->W : 0.0)));
                   CF_HIP(h, launch_upflow(h->coords1, B, h8, w8, 8, up, last ? flow_final : nullptr, h->H, h->W, h->padH, h->padW,
-                                          last ? flag : nullptr, su)); }
+                                          last ? flag : nullptr, su, last ? flow_low : nullptr));
+                  if (last) low_done = flow_low != nullptr; }
         } else if (last || up) {
             // mask = .25 * mask(net) (update.py:105) + learned convex up-sampling (eraft.py:77-88).  The reference
             // evaluates this on all 12 iterations; only iterations whose up-flow is requested are computed here.
@@ -1573,8 +1575,9 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
         }
     }
     if (up_pending) CF_HIP(h, hipStreamWaitEvent(st, h->ev_up, 0));
-    if (flow_low) {
-        // flow_init of the returned dict = coords1 - coords0 at 1/8 resolution (DCEIFlow.py:297)
+    if (flow_low && !low_done) {
+        // flow_init of the returned dict = coords1 - coords0 at 1/8 resolution (DCEIFlow.py:297); DCEIFlow folds it into the last
+        // iteration's upflow8 launch
         { PROF(h, st, "flow_low", 16.0 * B * N); CF_HIP(h, launch_upflow(h->coords1, B, h8, w8, 1, flow_low, nullptr, 0, 0, 0, 0, nullptr, st)); }
     }
     jg.disarm();

@@ -222,8 +222,9 @@ hipError_t launch_coords_init(float* coords1, const float* flow_init, int B, int
 // flow_up = ds * interpolate(coords1 - coords0, x ds, bilinear, align_corners=True)   (padded, nullable)
 // flow_final = unpad(flow_up)                                                          (nullable)
 // flag (nullable) |= any(flow_final != 0)
+// flow_low (nullable): additionally coords1 - coords0 on the 1/8 grid, by trailing blocks of the same launch
 hipError_t launch_upflow(const float* coords1, int B, int h8, int w8, int ds, float* flow_up,
-                         float* flow_final, int H, int W, int padH, int padW, int* flag, hipStream_t s);
+                         float* flow_final, int H, int W, int padH, int padW, int* flag, hipStream_t s, float* flow_low = nullptr);
 
 // learned convex x8 up-sampling (ERAFT/eraft.py:77-88, idn/idedeq.py:48-61): softmax over the 9 neighbours of
 // mask [B][N][576] (channel k*64 + i*8 + j) applied to unfold(8 * flow, 3x3, pad 1); flow = coords1 - coords0

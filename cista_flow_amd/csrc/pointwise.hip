@@ -688,9 +688,20 @@ hipError_t launch_coords_init(float* coords1, const float* flow_init, int B, int
 // then ImagePadder.unpad (image_process.py:103-107).  Also raises the ".any()" flag.
 // ---------------------------------------------------------------------------
 __global__ void upflow_kernel(const float* __restrict__ coords1, int B, int h8, int w8, int ds, float* flow_up,
-                              float* flow_final, int H, int W, int padH, int padW, int* flag) {
+                              float* flow_final, int H, int W, int padH, int padW, int* flag, float* flow_low, int nblk_main) {
     const int Hp = h8 * ds, Wp = w8 * ds;
     const long total = (long)B * 2 * Hp * Wp;
+    if ((int)blockIdx.x >= nblk_main) {
+        // trailing blocks: flow_low = coords1 - coords0 on the 1/8 grid (what a ds = 1 launch of this kernel computes: the bilinear
+        // weights are exactly 1 and 0 there), folded into the last iteration's launch
+        const long n = (long)h8 * w8, t = (long)(blockIdx.x - nblk_main) * blockDim.x + threadIdx.x;
+        if (t < (long)B * 2 * n) {
+            const int i = (int)(t % n), ch = (int)((t / n) % 2);
+            const float g = ch == 0 ? (float)(i % w8) : (float)(i / w8);
+            flow_low[t] = coords1[t] - g;            // = 1 * (1 * (1 * v + 0 * v') + 0 * (..)) of the general path for finite values
+        }
+        return;
+    }
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     bool nz = false;
     if (gid < total) {
@@ -723,13 +734,14 @@ __global__ void upflow_kernel(const float* __restrict__ coords1, int B, int h8, 
 }
 
 hipError_t launch_upflow(const float* coords1, int B, int h8, int w8, int ds, float* flow_up, float* flow_final, int H,
-                         int W, int padH, int padW, int* flag, hipStream_t s) {
+                         int W, int padH, int padW, int* flag, hipStream_t s, float* flow_low) {
     if (!coords1 || B <= 0 || h8 <= 0 || w8 <= 0 || ds <= 0) return hipErrorInvalidValue;
     if (flow_final && (H + padH != h8 * ds || W + padW != w8 * ds)) return hipErrorInvalidValue;
     const long total = (long)B * 2 * h8 * ds * w8 * ds;
-    note_launch("upflow_kernel", dim3((unsigned)((total + 255) / 256)), dim3(256));
-    hipLaunchKernelGGL(upflow_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, coords1, B, h8, w8, ds,
-                       flow_up, flow_final, H, W, padH, padW, flag);
+    const long nb_main = (total + 255) / 256, nb_low = flow_low ? ((long)B * 2 * h8 * w8 + 255) / 256 : 0;
+    note_launch("upflow_kernel", dim3((unsigned)(nb_main + nb_low)), dim3(256));
+    hipLaunchKernelGGL(upflow_kernel, dim3((unsigned)(nb_main + nb_low)), dim3(256), 0, s, coords1, B, h8, w8, ds,
+                       flow_up, flow_final, H, W, padH, padW, flag, flow_low, (int)nb_main);
     return hipGetLastError();
 }
 
