@@ -274,15 +274,19 @@ def test_buffer_reassignment_is_picked_up(gpu):
         assert gu.rel_err(f3.cpu(), f1.cpu()) < 1e-6
 
 
-def test_fused_pyramid_launch_is_bit_identical(gpu, monkeypatch):
-    """The one-launch correlation pyramid (levels 1..3 + coords1 init + flag reset, corr_pyramid_kernel) against the cascade of
-    corr_pool launches it replaces: same bits, with and without flow_init, odd map sizes (23 x 30 -> 11 x 15 -> 5 x 7 -> 2 x 3)."""
+@pytest.mark.parametrize("knob", ["CF_PYRAMID_FUSED", "CF_INORM_FUSED"])
+def test_fused_small_launches_are_bit_identical(gpu, monkeypatch, knob):
+    """Launch-count reductions on the dependent chains against the launches they replace, same bits:
+    CF_PYRAMID_FUSED -- the one-launch correlation pyramid (levels 1..3 + coords1 init + flag reset, corr_pyramid_kernel) vs the cascade
+    of corr_pool launches (odd map sizes: 23 x 30 -> 11 x 15 -> 5 x 7 -> 2 x 3), with flow_low riding in the last upflow8 launch;
+    CF_INORM_FUSED -- fold of the InstanceNorm partials + normalisation in one launch (inorm_fapply_kernel, encoder stages 2 / 3) vs
+    inorm_final + inorm_apply."""
     H, W, B = 180, 240, 2
     m = build_eiflow(H, W, 3, gpu)
     evs = [wu.synth_events(B, 5, H, W, 40 + i).to(gpu) for i in range(2)]
     outs = {}
     for fused in ("1", "0"):
-        monkeypatch.setenv("CF_PYRAMID_FUSED", fused)
+        monkeypatch.setenv(knob, fused)
         prev, st, res = torch.zeros(B, 1, H, W, device=gpu), None, []
         with torch.no_grad():
             for ev in evs:
