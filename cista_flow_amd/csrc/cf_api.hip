@@ -794,7 +794,9 @@ extern "C" int cf_finalize_weights(cf_handle* h, void* stream) {
             h->owned.push_back(pc.wino);
             for (int g = 0; g < pc.groups; ++g)
                 CF_HIP(h, launch_wino_weights(pc.w + (size_t)g * pc.rows * pc.Ktot, pc.wino + g * wf, pc.cout, pc.cin_pad, st));
-            if (h->cfg.precision == 0 && h->wino4) {      // F(4x4,3x3): four times the packed matrix
+            // F(4x4,3x3): four times the packed matrix -- only built when the opt-in kernel can be reached (CF_WINO4_MIN > 0, or a tool's
+            // CF_TILE_OVERRIDE)
+            if (h->cfg.precision == 0 && h->wino4 && (g_wino4_min > 0 || getenv("CF_TILE_OVERRIDE"))) {
                 const size_t wf4 = (size_t)wino4_weight_floats(pc.cout, pc.cin_pad);
                 CF_HIP(h, hipMalloc(reinterpret_cast<void**>(&pc.wino4), sizeof(float) * wf4 * pc.groups));
                 h->owned.push_back(pc.wino4);
