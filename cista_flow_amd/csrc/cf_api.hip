@@ -41,6 +41,7 @@ struct RawWeight {
 struct PackedConv {
     float* w = nullptr;
     float* wino = nullptr;   // Winograd F(2x2,3x3) transform of w (3x3 convs, fp32 and f16x3 modes; conv_wino_kernel)
+    float* wino16 = nullptr; // the F(2x2,3x3) transform in conv_wino16_kernel's order (3x3 convs, fp32 / f16x3 modes; CF_WINO16_MAX > 0)
     float* wino4 = nullptr;  // Winograd F(4x4,3x3) transform of w (3x3 convs, fp32 mode; conv_wino4_kernel)
     void* w16 = nullptr;     // f16 hi/lo split copy (precision != 0)
     float* bias = nullptr;
@@ -244,7 +245,7 @@ static hipError_t run_conv(cf_handle* h, const ConvParams& p_in, int batch, hipS
         if (p.aux3) p.aux3 += b0 * p.aux3_bs;
         if (p.addend) p.addend += b0 * p.addend_bs;
     }
-    if (h && !h->wino) { p.w_wino = nullptr; p.w_wino4 = nullptr; }
+    if (h && !h->wino) { p.w_wino = nullptr; p.w_wino4 = nullptr; p.w_wino16 = nullptr; }
     if (h && h->enc_tile_batch > 0) p.tile_batch = h->enc_tile_batch;
     if (p.w_div < 0 && h && h->enc_group_sel >= 0) {      // one network of a grouped PackedConv on its own: fixed matrix
         p.w += (long)h->enc_group_sel * p.w_bs;
@@ -252,7 +253,8 @@ static hipError_t run_conv(cf_handle* h, const ConvParams& p_in, int batch, hipS
         if (p.bias) p.bias += (long)h->enc_group_sel * p.bias_gs;
         if (p.w_wino) p.w_wino += (long)h->enc_group_sel * p.wino_gs;
         if (p.w_wino4) p.w_wino4 += (long)h->enc_group_sel * p.wino4_gs;
-        p.w_bs = 0; p.bias_gs = 0; p.w_div = 0; p.wino_gs = 0; p.wino4_gs = 0;
+        if (p.w_wino16) p.w_wino16 += (long)h->enc_group_sel * p.wino16_gs;
+        p.w_bs = 0; p.bias_gs = 0; p.w_div = 0; p.wino_gs = 0; p.wino4_gs = 0; p.wino16_gs = 0;
     }
     if (p.w_div < 0) {
         if (batch % (-p.w_div) != 0) return hipErrorInvalidValue;
@@ -473,12 +475,14 @@ ConvParams nhwc_conv(const PackedConv& pc, std::initializer_list<Seg> segs, int 
     p.w = pc.w; p.w16 = pc.w16; p.w_bs = 0; p.w_rows = pc.rows; p.Ktot = pc.Ktot; p.cin_pad = pc.cin_pad; p.bias = pc.bias;
     p.w_wino = pc.wino;
     p.w_wino4 = pc.wino4;
+    p.w_wino16 = pc.wino16;
     if (pc.groups > 1) {     // images [g*batch/groups, (g+1)*batch/groups) use matrix g; run_conv turns w_div into images per group
         p.w_bs = (long)pc.rows * pc.Ktot;
         p.bias_gs = pc.rows;
         p.w_div = -pc.groups;
         p.wino_gs = !pc.wino ? 0 : (pc.KH == 3 ? wino_weight_floats(pc.cout, pc.cin_pad) : wino1d_weight_floats(pc.cout, pc.cin_pad));
         p.wino4_gs = pc.wino4 ? wino4_weight_floats(pc.cout, pc.cin_pad) : 0;
+        p.wino16_gs = pc.wino16 ? wino16_weight_floats(pc.cout, pc.cin_pad) : 0;
     }
     p.out = out; p.out_ld = out_ld; p.out_bs = out_bs; p.cout = pc.cout; p.epi = epi;
     p.k_real = pc.cin * pc.KH * pc.KW;
@@ -794,6 +798,12 @@ extern "C" int cf_finalize_weights(cf_handle* h, void* stream) {
             h->owned.push_back(pc.wino);
             for (int g = 0; g < pc.groups; ++g)
                 CF_HIP(h, launch_wino_weights(pc.w + (size_t)g * pc.rows * pc.Ktot, pc.wino + g * wf, pc.cout, pc.cin_pad, st));
+            if (wino16_max() > 0) {      // the same U in conv_wino16_kernel's lane order
+                CF_HIP(h, hipMalloc(reinterpret_cast<void**>(&pc.wino16), sizeof(float) * wf * pc.groups));
+                h->owned.push_back(pc.wino16);
+                for (int g = 0; g < pc.groups; ++g)
+                    CF_HIP(h, launch_wino16_weights(pc.w + (size_t)g * pc.rows * pc.Ktot, pc.wino16 + g * wf, pc.cout, pc.cin_pad, st));
+            }
             // F(4x4,3x3): four times the packed matrix -- only built when the opt-in kernel can be reached (CF_WINO4_MIN > 0, or a tool's
             // CF_TILE_OVERRIDE)
             if (h->cfg.precision == 0 && h->wino4 && (g_wino4_min > 0 || getenv("CF_TILE_OVERRIDE"))) {
@@ -1984,6 +1994,12 @@ static int op_conv2d_impl(const float* in, int B, int Cin, int H, int W, const f
         if (hipMalloc(&wino.p, sizeof(float) * (size_t)wino1d_weight_floats(Cout, pc.cin_pad)) != hipSuccess) return CF_ERR_HIP;
         if (launch_wino1d_weights(pc.w, static_cast<float*>(wino.p), Cout, pc.cin_pad, st) != hipSuccess) return CF_ERR_HIP;
         p.w_wino = static_cast<float*>(wino.p);
+    }
+    TmpBuf wino16;
+    if (tile == 47 && !gather && KH == 3 && KW == 3) {
+        if (hipMalloc(&wino16.p, sizeof(float) * (size_t)wino16_weight_floats(Cout, pc.cin_pad)) != hipSuccess) return CF_ERR_HIP;
+        if (launch_wino16_weights(pc.w, static_cast<float*>(wino16.p), Cout, pc.cin_pad, st) != hipSuccess) return CF_ERR_HIP;
+        p.w_wino16 = static_cast<float*>(wino16.p);
     }
     TmpBuf part;
     if (stats_out) {   // fused InstanceNorm statistics

@@ -78,6 +78,8 @@ struct ConvParams {
     long wino_gs;       // floats between the Winograd matrices of consecutive weight groups (w_div)
     const float* w_wino4; // Winograd F(4x4,3x3) transform of w (launch_wino4_weights; nullable): enables tile 42
     long wino4_gs;
+    const float* w_wino16; // F(2x2,3x3) transform of w in conv_wino16_kernel's order (launch_wino16_weights; nullable): enables tile 47
+    long wino16_gs;
     const void* w16;    // f16 split copy of w (nullable; f16 modes fall back to splitting B while staging)
     long w_bs;          // weight stride between image groups (0 for ordinary weights; N*D for the correlation GEMM)
     int  w_div;         // images per weight group (<= 1: one matrix per image when w_bs != 0).  Two networks with the
@@ -132,6 +134,13 @@ long wino1d_weight_floats(int rows, int cin_pad);
 bool wino1d_ok(const ConvParams& p);
 long wino1d_workgroups(const ConvParams& p, long batch);
 hipError_t launch_wino1d(const ConvParams& p, int batch, hipStream_t s);
+// conv_wino16.hip, reached through launch_conv (tile 47): F(2x2,3x3) in half-size workgroups (16 tiles x 32 channels, 16x16x4 MFMA)
+hipError_t launch_wino16_weights(const float* w, float* u, int rows, int cin_pad, hipStream_t s);
+long wino16_weight_floats(int rows, int cin_pad);
+bool wino16_ok(const ConvParams& p);
+int wino16_regions(int Ho, int Wo);
+hipError_t launch_wino16(const ConvParams& p, int batch, hipStream_t s);
+long wino16_max();         // CF_WINO16_MAX (default 640; 0 = never take tile 47 and do not build its weights)
 // conv_patch.hip, reached through launch_conv (tile 43): planar small-Cin inputs (A_GATHER) with an LDS-resident input patch
 bool patch_ok(const ConvParams& p);
 int patch_tiles(int Ho, int Wo);

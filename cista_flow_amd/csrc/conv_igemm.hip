@@ -24,6 +24,10 @@ namespace cf {
 
 thread_local LaunchInfo g_last_launch = {"", 0};
 long g_wino4_min = 0;
+long wino16_max() {
+    static const long v = getenv("CF_WINO16_MAX") ? atol(getenv("CF_WINO16_MAX")) : 640;
+    return v;
+}
 
 // waves per SIMD the register allocation must leave room for (see conv_dma_kernel): what the main loop needs
 // (5 / 4 / 3 / 3 for 1 / 2 / 3 / 4 accumulator sub-tiles), capped by the LDS footprint of the two stage buffers
@@ -1426,6 +1430,7 @@ static int wino_regions(int Ho, int Wo) {
 int conv_stats_chunks(const ConvParams& p, int tile) {
     if (tile == 40 || tile == 41 || tile == 44 || tile == 45) return wino_regions(p.Ho, p.Wo) * 4;
     if (tile == 42) return wino4_regions(p.Ho, p.Wo) * 16;
+    if (tile == 47) return wino16_regions(p.Ho, p.Wo) * 2;
     if (tile == 43) return patch_tiles(p.Ho, p.Wo) * 4;
     return (p.Ho * p.Wo + 31) / 32;
 }
@@ -1714,6 +1719,7 @@ const char* conv_tile_name(int tile) {
         case 41: return "conv_wino8_kernel";
         case 42: return "conv_wino4_kernel";
         case 46: return "conv_wino1d_kernel";
+        case 47: return "conv_wino16_kernel";
         case 43: return "conv_patch_kernel";
         case 44: return "conv_wino_sk_kernel<2>";
         case 45: return "conv_wino_sk_kernel<4>";
@@ -1833,6 +1839,20 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
             else if (wg <= sk2_max) tile = 44;
         }
     }
+    // Half-size Winograd workgroups (tile 47, conv_wino16.hip: 16 tiles x 32 channels on the 16x16x4 MFMA) where conv_wino_kernel's
+    // 128-pixel workgroups are too few to spread over 256 CUs (tools/conv_bench.py, B = 8): above the single-round split-K range and
+    // up to CF_WINO16_MAX workgroups (convc2 288: 45 -> 39 us, fh.conv1 384: 26 -> 22.5, encoder stage 2 576: 28.5 -> 25.6; stage 1 with
+    // 1536 loses: 38 -> 40), and below conv_wino_kernel's own threshold instead of the direct kernel (convf2, 96: 21.7 -> 12.9 us)
+    static const int w16_kmin = getenv("CF_WINO16_KMIN") ? atoi(getenv("CF_WINO16_KMIN")) : 96;      // fewer channels: the doubled prologues / tails outweigh the better spread (cista-idnet's 32- and 64-channel layers: -0.8 % without this)
+    if (auto_tile && (tile == 40 || tile == 0) && p.cin_pad >= w16_kmin && wino16_ok(p) && wino16_max() > 0) {
+        const long tb = p.tile_batch > 0 ? p.tile_batch : batch;
+        const long wg = (long)wino_regions(p.Ho, p.Wo) * ((p.cout + 31) / 32) * tb;
+        const long wg16 = (long)wino16_regions(p.Ho, p.Wo) * ((p.cout + 31) / 32) * tb;
+        static const long sk2_max = getenv("CF_WINO_SK2_MAX") ? atol(getenv("CF_WINO_SK2_MAX")) : 256;
+        static const long w16min = getenv("CF_WINO16_MIN") ? atol(getenv("CF_WINO16_MIN")) : 96;
+        if (tile == 40 && wg > sk2_max && wg <= wino16_max()) tile = 47;
+        else if (tile == 0 && wg16 >= w16min) tile = 47;
+    }
     // 1x5 / 5x1 layers with transformed weights (the separable GRU): one-dimensional Winograd F(2,5), 1.67x fewer MFMAs (conv_wino1d.hip)
     if (tile == 0 && wino1d_ok(p)) {
         const long tb = p.tile_batch > 0 ? p.tile_batch : batch;
@@ -1898,7 +1918,7 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
                 tile = wgs128x128 >= 2304 ? 25 : ((p.cout >= 256 && p.cout % 128 == 0) ? 28 : 23);
         }
     }
-    if (((tile >= 20 && tile <= 42) || tile == 44 || tile == 45) && !(p.a_mode == A_NHWC && dma_range_ok(p))) return hipErrorInvalidValue;
+    if (((tile >= 20 && tile <= 42) || tile == 44 || tile == 45 || tile == 47) && !(p.a_mode == A_NHWC && dma_range_ok(p))) return hipErrorInvalidValue;
     if (tile == 43 && !patch_ok(p)) return hipErrorInvalidValue;   // explicit DMA tile, image too large
     if (tile_used) *tile_used = tile;
     g_last_launch.kernel = conv_tile_name(tile);
@@ -1945,6 +1965,7 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
         case 42: return launch_wino4(p, batch, s);
         case 43: return launch_patch(p, batch, s);
         case 46: return launch_wino1d(p, batch, s);
+        case 47: return launch_wino16(p, batch, s);
         case 44: return wino_ok(p) ? launch_wino_sk(p, batch, s, 2) : hipErrorInvalidValue;
         case 45: return wino_ok(p) ? launch_wino_sk(p, batch, s, 4) : hipErrorInvalidValue;
         default: return hipErrorInvalidValue;

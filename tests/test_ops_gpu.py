@@ -149,6 +149,8 @@ STATS_CASES = [
     (96, 96, 3, 3, 1, 1, 0, 42, 21, 37),     # ... ragged regions
     (64, 160, 3, 3, 1, 1, 0, 42, 17, 17),    # ... a small ragged map with B * Cout > 128 (partial-buffer sizing)
     (64, 160, 3, 3, 1, 1, 0, 40, 17, 17),
+    (96, 128, 3, 3, 1, 1, 0, 47, 13, 19),    # conv_wino16_kernel: two statistics patches per 8 x 8 region, ragged
+    (64, 64, 3, 3, 1, 1, 0, 47, 24, 32),
 ]
 
 
@@ -227,6 +229,10 @@ def test_conv_winograd(gpu, case):
         assert (gsk - ref).abs().max().item() < 1e-4, sk_tile
         assert (gsk - got).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), sk_tile
         assert torch.equal(gsk, run_conv(gpu, x, w, b, 1, 1, 1, pad_mode, 0, epi, sk_tile, H, W))
+    g16 = run_conv(gpu, x, w, b, 1, 1, 1, pad_mode, 0, epi, 47, H, W)      # half-size workgroups on the 16x16x4 MFMA (conv_wino16_kernel)
+    assert (g16 - ref).abs().max().item() < 1e-4
+    assert (g16 - got).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    assert torch.equal(g16, run_conv(gpu, x, w, b, 1, 1, 1, pad_mode, 0, epi, 47, H, W))
     if Cout % 64 == 0 and Cin % 16 == 0:       # the eight-wave kernel (tile 41): 64 output channels x 16-channel chunks
         got8 = run_conv(gpu, x, w, b, 1, 1, 1, pad_mode, 0, epi, 41, H, W)
         assert (got8 - ref).abs().max().item() < 1e-4
