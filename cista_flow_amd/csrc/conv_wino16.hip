@@ -31,6 +31,11 @@ __global__ __launch_bounds__(256, 4) void conv_wino16_kernel(const ConvParams p)
     __shared__ __attribute__((aligned(16))) float smem[W6_X + 64];       // ONE __shared__ object (see conv_wino_kernel)
     float* const sRaw = smem;
     int* const sMtab = reinterpret_cast<int*>(smem + W6_X);
+#ifdef CF_STAMP
+    const long long t_begin = __builtin_readcyclecounter();
+    const long long r_begin = (long long)__builtin_amdgcn_s_memrealtime();
+    long long st_wait = 0;
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -111,8 +116,14 @@ __global__ __launch_bounds__(256, 4) void conv_wino16_kernel(const ConvParams p)
     f32x4 bu[4];
     auto chunk_step = [&](int k) __attribute__((always_inline)) {
         // in flight, oldest first: the raw(k) piece, then the four U(k) loads
+#ifdef CF_STAMP
+        const long long t0 = __builtin_readcyclecounter();
+#endif
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         raw_barrier();                              // raw(k) has landed for everybody; everybody has read raw(k-1)
+#ifdef CF_STAMP
+        st_wait += __builtin_readcyclecounter() - t0;
+#endif
         const bool more = k + 1 < nchunk;
         issue_raw((k + 1) & 1, more);
         __builtin_amdgcn_sched_barrier(0);          // raw(k+1) before U(k+1) in issue order: the vmcnt(4) above counts on it
@@ -150,7 +161,13 @@ __global__ __launch_bounds__(256, 4) void conv_wino16_kernel(const ConvParams p)
 #pragma unroll
     for (int j = 0; j < 4; ++j) bu[j] = buf_load4(u_rsrc, uoff + 1024u * j, 0);
     __builtin_amdgcn_sched_barrier(0);
+#ifdef CF_STAMP
+    const long long t_loop_begin = __builtin_readcyclecounter();
+#endif
     for (int k = 0; k < nchunk; ++k) chunk_step(k);
+#ifdef CF_STAMP
+    const long long t_loop_end = __builtin_readcyclecounter();
+#endif
 
     __syncthreads();                                // every wave is done with the raw ring before it becomes the exchange buffer
     // ---- output transform, j direction (registers): R[0] = M0 + M1 + M2, R[1] = M1 - M2 - M3; C layout: row (tile) 4 kk + r, col t16 ----
@@ -195,6 +212,15 @@ __global__ __launch_bounds__(256, 4) void conv_wino16_kernel(const ConvParams p)
     const int pp = wave & 1, q0 = (wave >> 1) * 2;  // wave w finishes rows [16 (w >> 1), + 16) of patch w & 1
     patch_tail(p, smem + pp * (32 * EPI_S), b, 0, n0, lane, Ho * Wo, q0, q0 + 2, 1, 0, sMtab + pp * 32);
     if (p.st_partial && wave < 2) patch_stats(p, smem + wave * (32 * EPI_S), b, 0, n0, lane, Ho * Wo, sMtab + wave * 32, reg * 2 + wave, nreg * 2);
+#ifdef CF_STAMP
+    if (p.stamp && lane == 0) {      // [DMA wait + barrier, -, -, prologue, chunks, loop, tail, MHz] cycles of this wave
+        long long* q = p.stamp + ((long)blockIdx.x * 4 + wave) * 8;
+        q[0] = st_wait; q[1] = 0; q[2] = 0; q[3] = t_loop_begin - t_begin; q[4] = nchunk;
+        q[5] = t_loop_end - t_loop_begin; q[6] = __builtin_readcyclecounter() - t_loop_end;
+        const long long dr = (long long)__builtin_amdgcn_s_memrealtime() - r_begin;
+        q[7] = dr > 0 ? ((__builtin_readcyclecounter() - t_begin) * 100) / dr : 0;
+    }
+#endif
 }
 
 // U = G g G^T of a packed direct matrix w [rows][9 taps][cin_pad] in conv_wino16_kernel's order

@@ -180,7 +180,8 @@ __global__ __launch_bounds__(256, 4) void conv_wino1d_kernel(const ConvParams p)
     for (int j = 0; j < 3; ++j) bu[j] = buf_load4(u_rsrc, uoff + 2048u * j, 0);
     __builtin_amdgcn_sched_barrier(0);
     // (requesting raw and U TWO chunks ahead -- ring of three, two sets of U registers -- measured no faster: 34.8 vs 34.1 us; handing the
-    // chunks off in PAIRS -- ring of four, one barrier per two chunks, 48 KB of LDS -- measured slower: 36.0 vs 33.3 us, 1585 vs 1601 frames/s)
+    // chunks off in PAIRS -- ring of four, one barrier per two chunks, 48 KB of LDS -- measured slower: 36.0 vs 33.3 us, 1585 vs 1601 frames/s; reading and
+    // transforming chunk k + 1 in the shadow of chunk k's MFMAs -- 119 VGPRs -- measured no faster either: 35.3 us)
 #ifdef CF_STAMP
     const long long t_loop_begin = __builtin_readcyclecounter();
 #endif

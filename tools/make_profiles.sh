@@ -30,7 +30,7 @@ CF_LAYER_REPORT="$OUT/layers.txt" python bench.py --steps 20 --warmup 4 > "$OUT/
 python tools/collect_ktrace.py "$OUT/ktrace" "$OUT/layers.txt.json" "$OUT/ktrace_serial.txt" > /dev/null
 python tools/collect_traffic.py "$OUT/fetch" "$OUT/write" "$OUT/hbm_traffic.json" > "$OUT/traffic_top.txt"
 python tools/collect_mfma_busy.py "$OUT/mfma" "$OUT/mfma_busy.txt" > /dev/null
-CASES=zr.h:46,q.h:46,zr.v:46,zr.h:20,cista.D:40,cista.P:40,gates:40,out_gates:40,gates:42,cista.P:42,cista.D:42,cista.D:23,cista.P:28,gates:25,layer1:23,gru.zr:20,gru.q:22,convc2:20 CF_LIB_PATH=$ROOT/build_var/lib_stamp.so python tools/stamp_probe.py > "$OUT/stamps.txt" 2>&1 || true
+CASES=convc2:47,fh.conv1:47,layer2:47,zr.h:46,q.h:46,zr.v:46,zr.h:20,cista.D:40,cista.P:40,gates:40,out_gates:40,gates:42,cista.P:42,cista.D:42,cista.D:23,cista.P:28,gates:25,layer1:23,gru.zr:20,gru.q:22,convc2:20 CF_LIB_PATH=$ROOT/build_var/lib_stamp.so python tools/stamp_probe.py > "$OUT/stamps.txt" 2>&1 || true
 [ -x tools/probe/mfma_shape_probe.bin ] && tools/probe/mfma_shape_probe.bin > "$OUT/mfma_clock_probe.txt" 2>&1 || true
 # keep only the small summaries (the merge back is capped at 64 MiB)
 find "$OUT" -name "*counter_collection.csv" -delete
