@@ -50,7 +50,9 @@ def parse():
     ap.add_argument("--width", type=int, default=240)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=8)
+    ap.add_argument("--cpu-frames", type=int, default=10, help="timed CPU-baseline frames per batch size (after 2 warm-up frames)")
+    ap.add_argument("--repeat", type=int, default=3, help="timed blocks of --steps steps each; the MEDIAN block is reported")
+    ap.add_argument("--no-latency", action="store_true", help="skip the B = 1 / 2 / 4 legs (latency regime; N = 1 only)")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra f16x3-precision timing leg")
     ap.add_argument("--model", default="eiflow", choices=["eiflow", "eraft", "idnet"],
                     help="flow network (the BASELINE metric is eiflow; the others are extra workloads)")
@@ -63,25 +65,62 @@ def parse():
 def self_launch(a):
     """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the one-process-per-GPU job ourselves as a
     CHILD process (torch.distributed.run), before this process has made any HIP call -- a process that has touched the GPU
-    must never be replaced or fork GPU work -- relay rank 0's JSON line and exit with the child's return code."""
-    import socket
+    must never be replaced or fork GPU work -- relay rank 0's JSON line and exit with the child's return code.
+    --standalone lets the launcher pick its own free rendezvous port (no bind / close / re-bind window in which another
+    job on the shared network namespace could take it); the child's output is relayed line by line, so a hang is visible."""
     import subprocess
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(a.gpus), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", CF_BENCH_SELF_LAUNCHED="1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
-    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True)
-    for ln in r.stdout.splitlines():
+    proc = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for ln in proc.stdout:
+        ln = ln.rstrip("\n")
         if ln.startswith("{"):
             print(ln, flush=True)
         elif ln.strip():
             print(ln, file=sys.stderr, flush=True)
-    raise SystemExit(r.returncode)
+    raise SystemExit(proc.wait())
+
+
+def pin_rank_to_cores(local_rank, world):
+    """One rank per GPU enqueues ~300 launches per 5 ms step from ONE host thread: give every rank its own slice of the cores
+    this process may run on (before the first HIP call, so the runtime's helper threads inherit it).  No-op for a single
+    rank or where the platform has no sched_setaffinity."""
+    if world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        per = len(cpus) // world
+        if per < 1:
+            return None
+        mine = cpus[local_rank * per:(local_rank + 1) * per]
+        os.sched_setaffinity(0, mine)
+        return len(mine)
+    except OSError:
+        return None
+
+
+def cpu_info():
+    """(model string, physical cores this process may use) from /proc/cpuinfo + the affinity mask."""
+    model, phys = "unknown", set()
+    try:
+        allowed = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+        cur = {}
+        for ln in open("/proc/cpuinfo"):
+            if ":" in ln:
+                k, v = [t.strip() for t in ln.split(":", 1)]
+                cur[k] = v
+            elif cur:
+                if "model name" in cur:
+                    model = cur["model name"]
+                if allowed is None or int(cur.get("processor", -1)) in allowed:
+                    phys.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor", "0"))))
+                cur = {}
+    except OSError:
+        pass
+    return model, max(len(phys), 1)
 
 
 def model_args(H, W):
@@ -90,29 +129,40 @@ def model_args(H, W):
 
 
 def cpu_baseline(B, H, W, frames):
-    """The CPU oracle (port of the reference's eager fp32 graph) on the same workload, bounded sample."""
+    """The CPU oracle (port of the reference's eager fp32 graph) on the same workload, BASELINE.md section 3's protocol:
+    2 warm-up + `frames` (>= 10) timed frames of the recurrent loop, MEDIAN frame time, at B = 1 and at B = `B`; CPU model and
+    physical-core count in the record.  Threads: the GPU box's CPU share for one GPU is 16 cores (torch's default, all logical
+    CPUs of the host, oversubscribes it), so min(16, physical cores this process may use)."""
+    import statistics
     import weights_util as wu
     from oracle import cista_oracle as orc
     from cista_flow_amd.e2v.e2v_model import DCEIFlowCistaNet
     m = DCEIFlowCistaNet(model_args(H, W))
     wu.fill_module(m, 1234)
     sd = {k: v.clone() for k, v in m.state_dict().items()}
-    # the GPU box's CPU share for one GPU is 16 cores; torch's default (all 128 logical CPUs) oversubscribes
-    cores = min(16, os.cpu_count() or 1)
+    model_name, phys = cpu_info()
+    cores = min(16, phys)
     torch.set_num_threads(cores)
-    states, prev = None, torch.zeros(B, 1, H, W)
-    times = []
-    with torch.no_grad():
-        for t in range(frames + 1):
-            ev = wu.synth_events(B, 5, H, W, 1234 + t)
-            t0 = time.perf_counter()
-            I, _, states = orc.eiflow_step(sd, {"event_voxel": ev, "rec_img0": prev}, states)
-            times.append(time.perf_counter() - t0)
-            prev = I
-    timed = times[1:]
-    return {"value": round(B * len(timed) / sum(timed), 3), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d frames of the same B=%d %dx%d cista-eiflow workload after 1 warm-up frame "
-                      "(oracle/cista_oracle.py, eager PyTorch fp32, %d threads)" % (len(timed), B, H, W, cores)}
+    warm = 2
+
+    def leg(b):
+        states, prev = None, torch.zeros(b, 1, H, W)
+        times = []
+        with torch.no_grad():
+            for t in range(warm + frames):
+                ev = wu.synth_events(b, 5, H, W, 1234 + t)
+                t0 = time.perf_counter()
+                I, _, states = orc.eiflow_step(sd, {"event_voxel": ev, "rec_img0": prev}, states)
+                times.append(time.perf_counter() - t0)
+                prev = I
+        med = statistics.median(times[warm:])
+        return {"batch": b, "frames_per_s": round(b / med, 3), "median_ms_per_frame_step": round(med * 1e3, 1), "timed_frames": frames}
+
+    legs = [leg(1)] + ([leg(B)] if B != 1 else [])
+    return {"value": legs[-1]["frames_per_s"], "unit": "frames/s", "cores": cores, "kind": "port",
+            "cpu_model": model_name, "physical_cores_available": phys, "legs": legs,
+            "sample": "median of %d timed frames after %d warm-up frames of the recurrent %dx%d cista-eiflow loop, at B=1 and B=%d "
+                      "(value = the B=%d leg; oracle/cista_oracle.py, eager PyTorch fp32, %d threads)" % (frames, warm, H, W, B, B, cores)}
 
 
 PEAK_HBM_TBS = 8.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable with a float4 copy)
@@ -150,15 +200,17 @@ def roofline_pass(model, step, B, dev, nprof):
         return out
 
     def executed(r):
-        """flops the matrix cores execute for a launch-site row: Winograd F(2x2,3x3) launches do 16 products per 2x2 outputs
-        instead of the 36 of the 3x3 convolution they compute, i.e. 4/9 of the algorithmic flops; every other kernel all of them"""
-        return r["work"] * (4.0 / 9.0 if r["kernel"].startswith("conv_wino") else 1.0)
+        """flops the matrix cores execute for a launch-site row = algorithmic flops x the library's own per-tile ratio
+        (cf_conv_tile_mfma_ratio: 4/9 Winograd F(2x2,3x3), 0.6 F(2,5), 0.25 F(4x4,3x3), 1 for the direct kernels)"""
+        return r["work"] * r.get("mfma_ratio", 1.0)
 
     mf = agg(lambda r: r["class"] == "mfma")
     hb = agg(lambda r: r["class"] == "hbm")
     dom_name = max(mf, key=lambda k: mf[k]["ms"])
     dom = mf[dom_name]
-    ach = dom["work"] / (dom["ms"] * 1e-3) / 1e12
+    ach = dom["work"] / (dom["ms"] * 1e-3) / 1e12                     # algorithmic TFLOP/s
+    dom_exec = sum(executed(r) for r in rows if r["class"] == "mfma" and r["kernel"] == dom_name)
+    ach_x = dom_exec / (dom["ms"] * 1e-3) / 1e12                      # executed on the matrix cores
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
@@ -194,14 +246,15 @@ def roofline_pass(model, step, B, dev, nprof):
                 "time_weighted_frac": None if comb is None else round(comb, 4)}
 
     return {
-        "bound": "mfma", "kernel": dom_name, "achieved": round(ach, 2), "peak": round(mfma_peak(), 1),
-        "unit": "TFLOP/s", "frac": round(ach / mfma_peak(), 4), "traffic": traffic,
+        # `achieved` / `frac`: flops the matrix cores EXECUTE for the dominant kernel (a roofline fraction, <= 1); the algorithmic
+        # figure (2*M*N*9*Cin of the 3x3 convolution the reference computes; > executed for the Winograd kernels) stands beside it
+        "bound": "mfma", "kernel": dom_name, "achieved": round(ach_x, 2), "peak": round(mfma_peak(), 1),
+        "unit": "TFLOP/s", "frac": round(ach_x / mfma_peak(), 4),
+        "algorithmic_achieved": round(ach, 2), "algorithmic_frac": round(ach / mfma_peak(), 4),
+        "mfma_ratio": round(dom_exec / dom["work"], 4), "traffic": traffic,
         "note": "separate pass, HIP events on the launch stream, side streams folded into one stream (each kernel alone on the "
                 "chip), SAME launch grids as the timed step (half-batch CISTA chains kept, issued back to back)",
-        # conv_wino_kernel = Winograd F(2x2,3x3): `achieved` prices the ALGORITHMIC flops of the 3x3 convolution (2*M*N*9*Cin, what
-        # the reference executes); the matrix cores execute 16 products per 2x2 outputs instead of 36, i.e. 4/9 of that
-        "mfma_executed_tflops": round(ach * 4.0 / 9.0, 2) if dom_name.startswith("conv_wino") else round(ach, 2),
-        "mfma_executed_frac": round(ach * (4.0 / 9.0 if dom_name.startswith("conv_wino") else 1.0) / mfma_peak(), 4),
+        "mfma_executed_tflops": round(ach_x, 2), "mfma_executed_frac": round(ach_x / mfma_peak(), 4),     # (= achieved / frac; kept for continuity with r02 / r03 lines)
         "launches_per_step": dom["launches"] / nprof,
         "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
         "flops_per_launch": dom["work"] / dom["launches"],
@@ -210,7 +263,9 @@ def roofline_pass(model, step, B, dev, nprof):
                      "ms_per_step": round(mf_ms / nprof, 3),
                      "launches_per_step": sum(v["launches"] for v in mf.values()) / nprof, "gflop_per_step": round(mf_work / nprof / 1e9, 2)},
         "by_kernel": {k: {"ms_per_step": round(v["ms"] / nprof, 3), "tflops": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 2),
+                          "executed_tflops": round(sum(executed(r) for r in rows if r["class"] == "mfma" and r["kernel"] == k) / (v["ms"] * 1e-3) / 1e12, 2),
                           "launches_per_step": v["launches"] / nprof} for k, v in sorted(mf.items(), key=lambda kv: -kv[1]["ms"])},
+        "launches_per_step_all": sum(r["launches"] for r in rows) / nprof,
         # the HBM class: algorithmic bytes / HIP-event time against the 8 TB/s spec peak, per kernel and time-weighted
         "hbm": {"peak": PEAK_HBM_TBS, "unit": "TB/s", "achieved": round(hb_work / (hb_ms * 1e-3) / 1e12, 3) if hb_ms else None,
                 "frac": round(hb_work / (hb_ms * 1e-3) / 1e12 / PEAK_HBM_TBS, 4) if hb_ms else None,
@@ -238,6 +293,7 @@ def main():
         self_launch(a)                      # never returns
     if a.gpus != world:
         raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d" % (a.gpus, world, a.gpus))
+    pinned = pin_rank_to_cores(local_rank, world)       # before the first HIP call (torch.cuda.device_count() makes none on this image)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     # CF_BENCH_REHEARSE=1: control-flow rehearsal of the N > 1 path on a box with ONE GPU (all ranks share cuda:0,
@@ -315,27 +371,42 @@ def main():
                 state["gathered"] = collate_frames(I.cpu() if rehearse else I, n_sequences=a.strong or None, force=force_dist)
         return I
 
+    # W untimed warm-up steps, then `repeat` timed blocks of EXACTLY K steps each, every block bracketed by barrier +
+    # synchronize on both sides and reduced with MAX over the ranks; the MEDIAN block is the reported one (boxes and runs
+    # differ by +-2.5 %: one block of 20 steps = 100 ms is a thin sample)
+    blocks, my_blocks = [], []
     with torch.no_grad():
         for _ in range(max(a.warmup, 0)):
             step()
-        if dist_on:
-            torch.cuda.current_stream().wait_stream(side)
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            step()
-        if dist_on:
-            torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        if dist_on:
-            dist.barrier()
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
+        for _ in range(max(a.repeat, 1)):
+            if dist_on:
+                torch.cuda.current_stream().wait_stream(side)
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                step()
+            if dist_on:
+                torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            if dist_on:
+                dist.barrier()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            my_blocks.append(el)
+            if dist_on:
+                t = torch.tensor([el], device=cdev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            blocks.append(el)
+    el = sorted(blocks)[(len(blocks) - 1) // 2]           # median block (lower median for an even count)
+    # per-rank view of the same blocks (each rank's own clock around its median block): min / max over the ranks
+    my_ms = sorted(my_blocks)[(len(my_blocks) - 1) // 2] / a.steps * 1e3
+    rank_ms = [my_ms]
     if dist_on:
-        t = torch.tensor([el], device=cdev, dtype=torch.float64)
+        t = torch.tensor([my_ms, -my_ms], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+        rank_ms = [-float(t[1].item()), float(t[0].item())]
     assert torch.isfinite(state["prev"]).all(), "non-finite reconstruction"
 
     alt = None
@@ -389,12 +460,50 @@ def main():
     if not a.no_roofline and rank == 0:
         roofline = roofline_pass(model, step, B, dev, min(a.steps, 10))
 
+    # the latency regime the reference's own drivers run in (test_with_flow.py: B = 1): same step, smaller batches, N = 1 only
+    latency = None
+    if rank == 0 and world == 1 and not a.no_latency and not a.strong and B > 1:
+        latency = {}
+        for b in (1, 2, 4):
+            if b >= B:
+                continue
+            evb = [e[:b].contiguous() for e in evs]
+            stb = {"prev": torch.zeros(b, 1, H, W, device=dev), "states": None, "i": 0, "flow_init": None}
+
+            def stepb():
+                ev = evb[stb["i"] % R]
+                if a.model == "eiflow":
+                    I, bf, st = model({"event_voxel": ev, "rec_img0": stb["prev"]}, stb["states"], {})
+                elif a.model == "eraft":
+                    I, bf, st = model({"event_voxel": ev, "event_voxel_old": evb[(stb["i"] - 1) % R], "rec_img0": stb["prev"]}, stb["states"], {})
+                else:
+                    I, bf, st = model({"event_voxel": ev, "rec_img0": stb["prev"]}, stb["states"], stb["flow_init"], {})
+                    stb["flow_init"] = bf["next_flow"]
+                stb["prev"], stb["states"] = I, st
+                stb["i"] += 1
+
+            with torch.no_grad():
+                for _ in range(max(a.warmup, 2)):
+                    stepb()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(a.steps):
+                    stepb()
+                torch.cuda.synchronize()
+                elb = time.perf_counter() - t0
+            latency["b%d" % b] = {"frames_per_s": round(b * a.steps / elb, 1), "ms_per_step": round(elb / a.steps * 1e3, 3)}
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.model == "eiflow":
-        cpu = cpu_baseline(B, H, W, a.cpu_frames)
+        cpu = cpu_baseline(B, H, W, max(a.cpu_frames, 10))
 
     if rank == 0:
         value = total_seq * a.steps / el
+        if a.strong:      # ragged contiguous shards: say the range, not rank 0's size
+            sizes = [shard_range(a.strong, r, world)[1] - shard_range(a.strong, r, world)[0] for r in range(world)]
+            shard_desc = str(sizes[0]) if min(sizes) == max(sizes) else "%d..%d" % (min(sizes), max(sizes))
+        else:
+            shard_desc = str(B)
         rccl = None
         if dist_on and not rehearse:
             try:
@@ -404,16 +513,18 @@ def main():
         out = {
             "metric": "reconstructed frames/sec at %dx%d, cista-%s" % (H, W, a.model), "value": round(value, 2), "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 3),
+            "repeat": len(blocks), "block_ms_per_step": [round(b / a.steps * 1e3, 3) for b in blocks],
+            "rank_ms_per_step": {"min": round(rank_ms[0], 3), "max": round(rank_ms[-1], 3)}, "cores_pinned_per_rank": pinned,
             "higher_is_better": True, "scaling": "strong" if a.strong else "weak", "vs_baseline": None,
             "n_ranks_seen": dist.get_world_size() if dist_on else 1, "collective_backend": (("gloo (rehearsal)" if rehearse else "rccl " + str(rccl)) if dist_on else None),
             "dtype": {"f32": "f32", "f16x3": "f16x3->f32acc", "f16": "f16->f32acc"}[os.environ.get("CF_PRECISION", "f32")],
             "data": "synthetic",
-            "config": {"workload": "cista-%s %dx%d batch=%d sequences per GPU (BASELINE configs[%d]), flow iters %d, "
-                                   "CISTA depth 5, seeded random weights" % (a.model, H, W, B,
+            "config": {"workload": "cista-%s %dx%d batch=%s sequences per GPU (BASELINE configs[%d]), flow iters %d, "
+                                   "CISTA depth 5, seeded random weights" % (a.model, H, W, shard_desc,
                                                                             {"eiflow": 3 if (H, W) == (480, 640) else 1, "eraft": 2, "idnet": 4}[a.model],
                                                                             model.flow_iters),
-                       "sequences_per_gpu": B, "total_sequences": total_seq, "height": H, "width": W, "parallelism": "dp%d (independent sequences)" % world},
-            "roofline": roofline, "cpu_baseline": cpu, "alt_precision": alt,
+                       "sequences_per_gpu": int(shard_desc) if shard_desc.isdigit() else shard_desc, "total_sequences": total_seq, "height": H, "width": W, "parallelism": "dp%d (independent sequences)" % world},
+            "roofline": roofline, "cpu_baseline": cpu, "alt_precision": alt, "latency_regime": latency,
         }
         print(json.dumps(out), flush=True)
     if dist_on:

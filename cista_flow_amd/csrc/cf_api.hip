@@ -798,11 +798,12 @@ extern "C" int cf_finalize_weights(cf_handle* h, void* stream) {
             h->owned.push_back(pc.wino);
             for (int g = 0; g < pc.groups; ++g)
                 CF_HIP(h, launch_wino_weights(pc.w + (size_t)g * pc.rows * pc.Ktot, pc.wino + g * wf, pc.cout, pc.cin_pad, st));
-            if (wino16_max() > 0) {      // the same U in conv_wino16_kernel's lane order
-                CF_HIP(h, hipMalloc(reinterpret_cast<void**>(&pc.wino16), sizeof(float) * wf * pc.groups));
+            if (wino16_max() > 0) {      // the same U in conv_wino16_kernel's lane order; sized and group-strided with THAT kernel's block size
+                const size_t wf16 = (size_t)wino16_weight_floats(pc.cout, pc.cin_pad);       // (= nhwc_conv's wino16_gs)
+                CF_HIP(h, hipMalloc(reinterpret_cast<void**>(&pc.wino16), sizeof(float) * wf16 * pc.groups));
                 h->owned.push_back(pc.wino16);
                 for (int g = 0; g < pc.groups; ++g)
-                    CF_HIP(h, launch_wino16_weights(pc.w + (size_t)g * pc.rows * pc.Ktot, pc.wino16 + g * wf, pc.cout, pc.cin_pad, st));
+                    CF_HIP(h, launch_wino16_weights(pc.w + (size_t)g * pc.rows * pc.Ktot, pc.wino16 + g * wf16, pc.cout, pc.cin_pad, st));
             }
             // F(4x4,3x3): four times the packed matrix -- only built when the opt-in kernel can be reached (CF_WINO4_MIN > 0, or a tool's
             // CF_TILE_OVERRIDE)
@@ -1021,8 +1022,9 @@ extern "C" int cf_profile_read(cf_handle* h, double* ms, double* flops, long lon
         snprintf(line, sizeof(line), "%-44s %-40s grid %9ld launches %6ld  ms %9.3f  avg_us %8.2f  %s %8.3f\n", a.tag.c_str(),
                  a.kernel.c_str(), a.threads, a.cnt, a.ms, a.ms * 1e3 / a.cnt, a.cls == 0 ? "TFLOP/s" : "TB/s   ", rate);
         h->prof_report += line;
-        snprintf(line, sizeof(line), "%s{\"tag\":\"%s\",\"kernel\":\"%s\",\"grid\":%ld,\"class\":\"%s\",\"launches\":%ld,\"ms\":%.6f,\"work\":%.6e}",
-                 first ? "" : ",", a.tag.c_str(), a.kernel.c_str(), a.threads, a.cls == 0 ? "mfma" : "hbm", a.cnt, a.ms, a.work);
+        snprintf(line, sizeof(line), "%s{\"tag\":\"%s\",\"kernel\":\"%s\",\"grid\":%ld,\"class\":\"%s\",\"launches\":%ld,\"ms\":%.6f,\"work\":%.6e,\"tile\":%d,\"mfma_ratio\":%.6f}",
+                 first ? "" : ",", a.tag.c_str(), a.kernel.c_str(), a.threads, a.cls == 0 ? "mfma" : "hbm", a.cnt, a.ms, a.work, a.tile,
+                 a.cls == 0 ? conv_tile_mfma_ratio(a.tile) : 1.0);
         h->prof_json += line;
         first = false;
     }
@@ -1033,10 +1035,12 @@ extern "C" int cf_profile_read(cf_handle* h, double* ms, double* flops, long lon
 // per-layer table of the last cf_profile_read (layer tag, kernel, grid, launches, time, achieved TFLOP/s or TB/s)
 extern "C" const char* cf_profile_report(const cf_handle* h) { return h ? h->prof_report.c_str() : ""; }
 // the same rows as JSON: [{tag, kernel, grid (work-items = rocprofv3 Grid_Size), class "mfma"|"hbm", launches, ms (sum),
-// work (sum of algorithmic flops or bytes)}]
+// work (sum of algorithmic flops or bytes), tile (conv tile kind, 0 for the HBM class), mfma_ratio (executed / algorithmic flops of that
+// tile's kernel: 4/9 Winograd F(2x2,3x3), 0.6 F(2,5), 0.25 F(4x4,3x3), 1 direct)}]
 extern "C" const char* cf_profile_report_json(const cf_handle* h) { return h ? h->prof_json.c_str() : "[]"; }
 
 extern "C" const char* cf_conv_tile_name(int tile) { return conv_tile_name(tile); }
+extern "C" double cf_conv_tile_mfma_ratio(int tile) { return conv_tile_mfma_ratio(tile); }
 
 // ---------------------------------------------------------------------------------------------
 // a4 warp
@@ -1985,7 +1989,7 @@ static int op_conv2d_impl(const float* in, int B, int Cin, int H, int W, const f
         p.w_wino4 = static_cast<float*>(wino4.p);
     }
     TmpBuf wino;
-    if ((tile == 40 || tile == 41 || tile == 44 || tile == 45) && !gather && KH == 3 && KW == 3) {      // Winograd tile: needs the transformed weights
+    if ((tile == 40 || tile == 41 || tile == 44 || tile == 45 || tile == 48) && !gather && KH == 3 && KW == 3) {      // Winograd tile: needs the transformed weights
         if (hipMalloc(&wino.p, sizeof(float) * (size_t)wino_weight_floats(Cout, pc.cin_pad)) != hipSuccess) return CF_ERR_HIP;
         if (launch_wino_weights(pc.w, static_cast<float*>(wino.p), Cout, pc.cin_pad, st) != hipSuccess) return CF_ERR_HIP;
         p.w_wino = static_cast<float*>(wino.p);

@@ -119,6 +119,7 @@ struct ConvParams {
 // tile: 0 auto, else explicit (see conv_igemm.hip); tile_used (nullable) returns the choice
 hipError_t launch_conv(const ConvParams& p, int batch, hipStream_t s, int tile = 0, int* tile_used = nullptr);
 const char* conv_tile_name(int tile);
+double conv_tile_mfma_ratio(int tile);      // executed / algorithmic flops of that tile's kernel (Winograd forms < 1)
 // U = G g G^T of a packed 3x3 matrix [rows][9][cin_pad] in conv_wino_kernel's block layout (wino_weight_floats floats)
 hipError_t launch_wino_weights(const float* w, float* u, int rows, int cin_pad, hipStream_t s);
 long wino_weight_floats(int rows, int cin_pad);
@@ -140,6 +141,10 @@ long wino16_weight_floats(int rows, int cin_pad);
 bool wino16_ok(const ConvParams& p);
 int wino16_regions(int Ho, int Wo);
 hipError_t launch_wino16(const ConvParams& p, int batch, hipStream_t s);
+// conv_wino_p.hip, reached through launch_conv (tile 48): conv_wino_kernel's arithmetic in persistent workgroups that walk several regions
+bool wino_p_ok(const ConvParams& p);
+int wino_p_walkers(const ConvParams& p, long NR);
+hipError_t launch_wino_p(const ConvParams& p, int batch, hipStream_t s);
 long wino16_max();         // CF_WINO16_MAX (default 640; 0 = never take tile 47 and do not build its weights)
 // conv_patch.hip, reached through launch_conv (tile 43): planar small-Cin inputs (A_GATHER) with an LDS-resident input patch
 bool patch_ok(const ConvParams& p);

@@ -62,13 +62,21 @@ __device__ __forceinline__ const float* sel3(const float* const (&a)[3], int s) 
 }
 
 
+// The fused-epilogue helpers below are templates over the parameter block's type CP: ConvParams itself (the by-value kernel argument,
+// whose fields the compiler loads once, wherever it likes) or `const __attribute__((address_space(4))) ConvParams` read through a
+// laundered kernarg-segment pointer (KernargParams below): conv_wino_p_kernel runs its tail INSIDE a loop, and with the by-value
+// argument every field the tail touches would be hoisted out of that loop and held in SGPRs across the MFMA loop (183 SGPR spills).
+typedef const __attribute__((address_space(4))) ConvParams KernargParams;
+
 // weight / bias group of image b (ConvParams::w_div)
-__device__ __forceinline__ int wgroup(const ConvParams& p, int b) { return p.w_div > 1 ? b / p.w_div : b; }
+template <class CP>
+__device__ __forceinline__ int wgroup(const CP& p, int b) { return p.w_div > 1 ? b / p.w_div : b; }
 
 static constexpr int EPI_S = 36;   // per-wave epilogue patch row stride (floats)
 
 // Element-wise tail of one conv output quad: pixel m, couts n..n+3 (n % 4 == 0).
-__device__ __forceinline__ void epilogue4(const ConvParams& p, int b, int m, int n, f32x4 acc) {
+template <class CP>
+__device__ __forceinline__ void epilogue4(const CP& p, int b, int m, int n, f32x4 acc) {
     const int nv = (p.cout - n) < 4 ? (p.cout - n) : 4;      // valid couts in this quad
     const bool full = nv == 4;
     f32x4 v = acc;
@@ -248,8 +256,8 @@ __device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned of
 // sum of nparts partial patches pstride floats apart (split-K tiles: every wave finishes its share of the rows).
 // mtab (nullable, LDS): row r of the patch is output pixel mtab[r] (< 0: no pixel) instead of mrow0 + r -- tiles whose rows
 // are not consecutive pixels (the Winograd kernel's 2x2 output blocks)
-template <int EB, int CLS>
-__device__ __forceinline__ void patch_tail_fast(const ConvParams& p, const float* sW, int b, int mrow0, int nbase, int lane,
+template <int EB, int CLS, class CP>
+__device__ __forceinline__ void patch_tail_fast(const CP& p, const float* sW, int b, int mrow0, int nbase, int lane,
                                                 int M, int it0, int it1, int nparts, int pstride, const int* mtab = nullptr) {
     const int n = nbase + (lane & 7) * 4;
     const int mb = mrow0 + (lane >> 3);
@@ -446,7 +454,8 @@ __device__ __forceinline__ void patch_tail_fast(const ConvParams& p, const float
 }
 
 // generic tail: any alignment, partial quads, strided outputs (out_cs != 1), EPI_ADD_AUX
-__device__ __forceinline__ void patch_tail(const ConvParams& p, const float* sW, int b, int mrow0, int nbase, int lane, int M,
+template <class CP>
+__device__ __forceinline__ void patch_tail(const CP& p, const float* sW, int b, int mrow0, int nbase, int lane, int M,
                                            int it0 = 0, int it1 = 4, int nparts = 1, int pstride = 0, const int* mtab = nullptr) {
     if (p.epi_vec && nbase + 32 <= p.cout) {      // wave-uniform
         const int epi = p.epi;
@@ -491,7 +500,8 @@ __device__ __forceinline__ void patch_tail(const ConvParams& p, const float* sW,
 // v = acc + bias exactly as stored, and written to st_partial[b][patch][cout][2] (every element once).
 // mtab (nullable): row validity comes from the row -> pixel table and the patch is number `patch_id` of `npatch_` per image
 // (Winograd tiles); otherwise rows mrow0.. of the image and patch number mrow0 / 32 of ceil(M / 32)
-__device__ __forceinline__ void patch_stats(const ConvParams& p, const float* sW, int b, int mrow0, int nbase, int lane,
+template <class CP>
+__device__ __forceinline__ void patch_stats(const CP& p, const float* sW, int b, int mrow0, int nbase, int lane,
                                             int M, const int* mtab = nullptr, int patch_id = 0, int npatch_ = 0) {
     const int c = lane & 31, half = lane >> 5;
     const int n = nbase + c;

@@ -1125,6 +1125,9 @@ __global__ __launch_bounds__(256, 4) void conv_wino_kernel(const ConvParams p) {
         return;
     }
 #endif
+    // the last chunk step's dead past-the-end DMA (zeros into the ring) must have landed before anything overlays the ring: an explicit
+    // wait, so that this does not rest on the compiler's LDS-DMA bookkeeping in front of the barrier
+    wait_vmcnt0();
     __syncthreads();                                // every wave is done with the raw ring before it becomes the exchange buffer
     // ---- output transform, j direction (in registers): R[0] = M0 + M1 + M2, R[1] = M1 - M2 - M3 ----
     float* X = smem;                                // X[i = wave][bcol][tile 32][cout 32], over the raw ring
@@ -1344,6 +1347,7 @@ __global__ __launch_bounds__(512, 4) void conv_wino8_kernel(const ConvParams p) 
     issue_raw(0);
     for (int k = 0; k < nchunk; ++k) chunk_step(k);
 
+    wait_vmcnt0();                                  // the dead past-the-end DMA of the last chunk step has landed (explicit: ADVICE r3)
     __syncthreads();                                // every wave is done with V before it becomes the exchange buffer
     float* X = smem;                                // X[wave][bcol][tile 32][cout 32]
 #pragma unroll
@@ -1428,7 +1432,7 @@ static int wino_regions(int Ho, int Wo) {
 
 // statistics partials a convolution with st_partial writes per image: one per 32-pixel patch, or per Winograd tile row
 int conv_stats_chunks(const ConvParams& p, int tile) {
-    if (tile == 40 || tile == 41 || tile == 44 || tile == 45) return wino_regions(p.Ho, p.Wo) * 4;
+    if (tile == 40 || tile == 41 || tile == 44 || tile == 45 || tile == 48) return wino_regions(p.Ho, p.Wo) * 4;
     if (tile == 42) return wino4_regions(p.Ho, p.Wo) * 16;
     if (tile == 47) return wino16_regions(p.Ho, p.Wo) * 2;
     if (tile == 43) return patch_tiles(p.Ho, p.Wo) * 4;
@@ -1720,10 +1724,23 @@ const char* conv_tile_name(int tile) {
         case 42: return "conv_wino4_kernel";
         case 46: return "conv_wino1d_kernel";
         case 47: return "conv_wino16_kernel";
+        case 48: return "conv_wino_p_kernel";
         case 43: return "conv_patch_kernel";
         case 44: return "conv_wino_sk_kernel<2>";
         case 45: return "conv_wino_sk_kernel<4>";
         default: return "?";
+    }
+}
+
+// Fraction of a convolution's ALGORITHMIC flops (2 M N taps Cin: what the reference computes) that the kernel of tile kind `tile`
+// executes on the matrix cores: 16 / 36 for Winograd F(2x2,3x3), 6 / 10 for the one-dimensional F(2,5), 36 / 144 for F(4x4,3x3), 1 for the
+// direct kernels.  bench.py prices the executed-MFMA roofline fraction with it (per launch-site row, not by kernel-name prefix).
+double conv_tile_mfma_ratio(int tile) {
+    switch (tile) {
+        case 40: case 41: case 44: case 45: case 47: case 48: return 4.0 / 9.0;
+        case 46: return 0.6;
+        case 42: return 0.25;
+        default: return 1.0;
     }
 }
 
@@ -1867,6 +1884,14 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
         const long w4min = g_wino4_min;             // cf_create reads CF_WINO4_MIN (0 = never: the default)
         if (w4min > 0 && wg >= w4min) tile = 42;
     }
+    // conv_wino_kernel's launches as persistent workgroups (tile 48, conv_wino_p.hip: bit-identical results).  OFF by default: measured
+    // (r04, one box, three alternating pairs) 1599-1601 frames/s with tile 40 against 1585-1590 with tile 48, and +-3 % per layer either way
+    // (tools/r4_winop.sh): with four workgroups resident per CU the hardware dispatcher already starts a fresh workgroup's prologue
+    // beside the other three's MFMAs, which is all the walk buys.  CF_WINOP=1 turns it on.
+    if (auto_tile && tile == 40 && wino_p_ok(p)) {
+        static const int winop = getenv("CF_WINOP") ? atoi(getenv("CF_WINOP")) : 0;
+        if (winop) tile = 48;
+    }
     if (tile == 0) {
         // Pick the largest tile that still yields >= ~2 workgroups per CU (measured with tools/conv_bench.py on
         // MI355X): big tiles reuse operands best, but a launch with fewer than ~512 workgroups leaves CUs idle,
@@ -1918,7 +1943,7 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
                 tile = wgs128x128 >= 2304 ? 25 : ((p.cout >= 256 && p.cout % 128 == 0) ? 28 : 23);
         }
     }
-    if (((tile >= 20 && tile <= 42) || tile == 44 || tile == 45 || tile == 47) && !(p.a_mode == A_NHWC && dma_range_ok(p))) return hipErrorInvalidValue;
+    if (((tile >= 20 && tile <= 42) || tile == 44 || tile == 45 || tile == 47 || tile == 48) && !(p.a_mode == A_NHWC && dma_range_ok(p))) return hipErrorInvalidValue;
     if (tile == 43 && !patch_ok(p)) return hipErrorInvalidValue;   // explicit DMA tile, image too large
     if (tile_used) *tile_used = tile;
     g_last_launch.kernel = conv_tile_name(tile);
@@ -1966,6 +1991,7 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
         case 43: return launch_patch(p, batch, s);
         case 46: return launch_wino1d(p, batch, s);
         case 47: return launch_wino16(p, batch, s);
+        case 48: return launch_wino_p(p, batch, s);
         case 44: return wino_ok(p) ? launch_wino_sk(p, batch, s, 2) : hipErrorInvalidValue;
         case 45: return wino_ok(p) ? launch_wino_sk(p, batch, s, 4) : hipErrorInvalidValue;
         default: return hipErrorInvalidValue;

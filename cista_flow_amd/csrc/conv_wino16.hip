@@ -169,6 +169,9 @@ __global__ __launch_bounds__(256, 4) void conv_wino16_kernel(const ConvParams p)
     const long long t_loop_end = __builtin_readcyclecounter();
 #endif
 
+    // the last chunk step's dead past-the-end DMA (zeros into the ring) must have landed before anything overlays the ring: an explicit
+    // wait, so that this does not rest on the compiler's LDS-DMA bookkeeping in front of the barrier
+    wait_vmcnt0();
     __syncthreads();                                // every wave is done with the raw ring before it becomes the exchange buffer
     // ---- output transform, j direction (registers): R[0] = M0 + M1 + M2, R[1] = M1 - M2 - M3; C layout: row (tile) 4 kk + r, col t16 ----
     float* X = smem;                                // X[i = wave][bcol][tile 16][cout 32]

@@ -190,6 +190,9 @@ __global__ __launch_bounds__(256, 4) void conv_wino1d_kernel(const ConvParams p)
     const long long t_loop_end = __builtin_readcyclecounter();
 #endif
 
+    // the last chunk step's dead past-the-end DMA (zeros into the ring) must have landed before anything overlays the ring: an explicit
+    // wait, so that this does not rest on the compiler's LDS-DMA bookkeeping in front of the barrier
+    wait_vmcnt0();
     __syncthreads();                                // every wave is done with the raw ring before the patches go on top of it
     // ---- this wave's columns of A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 1]: two partial patches [tile][cout], row stride EPI_S ----
     float* const sP = smem + wave * 2 * W1_P;

@@ -327,6 +327,9 @@ __device__ __forceinline__ void wino4_body(const ConvParams& p, float* smem) {
         q[7] = dr > 0 ? ((__builtin_readcyclecounter() - t_begin) * 100) / dr : 0;
     }
 #endif
+    // the last chunk step's dead past-the-end DMA (zeros into the ring) must have landed before anything overlays the ring: an explicit
+    // wait, so that this does not rest on the compiler's LDS-DMA bookkeeping in front of the barrier
+    wait_vmcnt0();
     __syncthreads();                                // every wave is done with the raw ring before it becomes the exchange buffer
     // ---- output transform.  Along j in registers, IN PLACE (acc[j'] <- sum_j A^T[j'][j] M[i][j], j' = 0..3); along i across the
     // waves through LDS, two output columns j' per round: X[i = wave][2][tile 32][cout 32] = 48 KB.  Waves 0..3 (= output row i')

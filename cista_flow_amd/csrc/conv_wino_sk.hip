@@ -167,6 +167,7 @@ __global__ __launch_bounds__(256 * SK, SK == 2 ? 4 : 4) void conv_wino_sk_kernel
     __builtin_amdgcn_sched_barrier(0);
     for (int s = 0; s < nstep; ++s) step(s);
 
+    wait_vmcnt0();                                  // the dead past-the-end DMA of the last chunk step has landed (explicit: ADVICE r3)
     __syncthreads();                                // every wave of every group is done with its raw ring
     // ---- output transform, j direction (registers) into this group's exchange block X[g][i = wave][bcol][tile][cout] ----
     float* X = smem + grp * WG_A;

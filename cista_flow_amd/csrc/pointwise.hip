@@ -619,6 +619,7 @@ long corr_pyramid_lds_bytes(int H0, int W0) {
 hipError_t launch_corr_pyramid(const float* l0, float* l1, float* l2, float* l3, long rows, int H0, int W0, float* coords1,
                                const float* flow_init, int B, int h8, int w8, int* flag, hipStream_t s) {
     if (!l0 || !l1 || !l2 || !l3 || rows <= 0 || H0 < 8 || W0 < 8) return hipErrorInvalidValue;
+    if (flag && !coords1) return hipErrorInvalidValue;      // the flag is cleared by the trailing coords-init blocks: none without coords1
     const long lds = corr_pyramid_lds_bytes(H0, W0);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     const long nb_pool = (rows + 3) / 4;
@@ -836,6 +837,7 @@ hipError_t launch_upflow(const float* coords1, int B, int h8, int w8, int ds, fl
     if (flow_final && (H + padH != h8 * ds || W + padW != w8 * ds)) return hipErrorInvalidValue;
     const long total = (long)B * 2 * h8 * ds * w8 * ds;
     const long nb_main = (total + 255) / 256, nb_low = flow_low ? ((long)B * 2 * h8 * w8 + 255) / 256 : 0;
+    if (nb_main + nb_low >= 0x7FFFFFFFL) return hipErrorInvalidValue;      // nb_main travels as an int, the grid is unsigned
     note_launch("upflow_kernel", dim3((unsigned)(nb_main + nb_low)), dim3(256));
     hipLaunchKernelGGL(upflow_kernel, dim3((unsigned)(nb_main + nb_low)), dim3(256), 0, s, coords1, B, h8, w8, ds,
                        flow_up, flow_final, H, W, padH, padW, flag, flow_low, (int)nb_main);

@@ -22,6 +22,7 @@ SYMBOLS = [
     "cf_op_nhwc_to_nchw", "cf_profile_enable", "cf_profile_read", "cf_conv_tile_name", "cf_profile_report", "cf_op_conv2d_bench", "cf_events_to_voxel", "cf_op_conv2d_inorm_stats", "cf_quantize_u8", "cf_hint_prev_grid",
     "cf_profile_report_json", "cf_metrics_scratch_doubles", "cf_metrics_recon", "cf_metrics_flow", "cf_metrics_fwl",
     "cf_graph_enable", "cf_graph_stats", "cf_events_to_voxel_ex", "cf_voxel_preprocess", "cf_metrics_ssim",
+    "cf_conv_tile_mfma_ratio",
 ]
 
 
@@ -119,6 +120,8 @@ def load():
     lib.cf_profile_report_json.restype = C.c_char_p
     lib.cf_conv_tile_name.argtypes = [i]
     lib.cf_conv_tile_name.restype = C.c_char_p
+    lib.cf_conv_tile_mfma_ratio.argtypes = [i]
+    lib.cf_conv_tile_mfma_ratio.restype = C.c_double
     _lib = lib
     return lib
 

@@ -188,6 +188,10 @@ int cf_metrics_ssim(const float* rec, const float* target, int planes, int H, in
 int cf_profile_enable(cf_handle* h, int on);
 int cf_profile_read(cf_handle* h, double* ms, double* flops, long long* count, int n);
 const char* cf_conv_tile_name(int tile);
+/* executed / algorithmic matrix-core flops of that tile kind's kernel (4/9 Winograd F(2x2,3x3), 0.6 F(2,5), 0.25 F(4x4,3x3), 1 direct):
+ * the rows of cf_profile_report_json carry it as "mfma_ratio" next to "tile", so the executed-MFMA roofline fraction is priced per
+ * launch site from the library's own table */
+double cf_conv_tile_mfma_ratio(int tile);
 /* per-layer text table of the last cf_profile_read (layer, tile kind, launches, ms, TFLOP/s) */
 const char* cf_profile_report(const cf_handle* h);
 const char* cf_profile_report_json(const cf_handle* h);

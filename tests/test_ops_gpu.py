@@ -149,6 +149,8 @@ STATS_CASES = [
     (96, 96, 3, 3, 1, 1, 0, 42, 21, 37),     # ... ragged regions
     (64, 160, 3, 3, 1, 1, 0, 42, 17, 17),    # ... a small ragged map with B * Cout > 128 (partial-buffer sizing)
     (64, 160, 3, 3, 1, 1, 0, 40, 17, 17),
+    (64, 64, 3, 3, 1, 1, 0, 48, 48, 64),     # persistent Winograd workgroups: the partials of every item a walker carries
+    (96, 96, 3, 3, 1, 1, 0, 48, 21, 37),
     (96, 128, 3, 3, 1, 1, 0, 47, 13, 19),    # conv_wino16_kernel: two statistics patches per 8 x 8 region, ragged
     (64, 64, 3, 3, 1, 1, 0, 47, 24, 32),
 ]
@@ -224,6 +226,17 @@ def test_conv_winograd(gpu, case):
     assert got.shape == ref.shape
     assert (got - ref).abs().max().item() < 1e-4
     assert (got - direct).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    # persistent workgroups (tile 48, conv_wino_p_kernel): the same arithmetic, bit for bit -- with the default grid (one item per
+    # walker at these sizes) and with the grid shrunk to one walker per (XCD, n-block), which then walks its XCD's whole run of regions
+    import os
+    gp = run_conv(gpu, x, w, b, 1, 1, 1, pad_mode, 0, epi, 48, H, W)
+    assert torch.equal(gp, got)
+    os.environ["CF_WINOP_SLOTS"] = "8"
+    try:
+        gp1 = run_conv(gpu, x, w, b, 1, 1, 1, pad_mode, 0, epi, 48, H, W)
+    finally:
+        del os.environ["CF_WINOP_SLOTS"]
+    assert torch.equal(gp1, got)
     for sk_tile in (44, 45):                   # chunks split over 2 / 4 wave groups of a workgroup (odd chunk counts: dead steps)
         gsk = run_conv(gpu, x, w, b, 1, 1, 1, pad_mode, 0, epi, sk_tile, H, W)
         assert (gsk - ref).abs().max().item() < 1e-4, sk_tile

@@ -20,6 +20,46 @@ def test_shard_range_covers_everything():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_config3_split_is_four_sequences_per_rank():
+    """BASELINE configs[3]: 32 sequences of 480x640 over 8 ranks (`bench.py --gpus 8 --strong 32`): every rank holds exactly 4
+    consecutive sequences, in rank order, and a padded all-gather of 4-row shards collates them without a gap."""
+    spans = [shard_range(32, r, 8) for r in range(8)]
+    assert spans == [(4 * r, 4 * r + 4) for r in range(8)]
+    # ragged totals near it keep the contiguous, at-most-one-apart property bench.py's padded all-gather relies on
+    for n in (31, 33, 35):
+        sizes = [shard_range(n, r, 8)[1] - shard_range(n, r, 8)[0] for r in range(8)]
+        assert sum(sizes) == n and max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+
+def test_bench_pins_each_rank_to_its_own_cores():
+    """bench.pin_rank_to_cores: disjoint, equal slices of the cores the process may use, one per local rank; a no-op for one rank."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    if not hasattr(os, "sched_getaffinity"):
+        import pytest
+        pytest.skip("no sched_setaffinity on this platform")
+    before = os.sched_getaffinity(0)
+    try:
+        assert bench.pin_rank_to_cores(0, 1) is None and os.sched_getaffinity(0) == before
+        world = 2 if len(before) >= 2 else 1
+        seen = []
+        for r in range(world):
+            os.sched_setaffinity(0, before)
+            n = bench.pin_rank_to_cores(r, world)
+            if world > 1:
+                mine = os.sched_getaffinity(0)
+                assert n == len(mine) == len(before) // world and mine <= before
+                assert all(not (mine & o) for o in seen)
+                seen.append(mine)
+    finally:
+        os.sched_setaffinity(0, before)
+    model, phys = bench.cpu_info()
+    assert isinstance(model, str) and phys >= 1
+
+
 def _worker(rank, world, port, n_seq, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -87,7 +127,7 @@ def test_traffic_table_uses_the_library_kernel_names():
     import json
     from cista_flow_amd import lib
     L = lib.load()
-    names = {L.cf_conv_tile_name(t).decode() for t in range(1, 48)}
+    names = {L.cf_conv_tile_name(t).decode() for t in range(1, 49)}
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     table = json.load(open(os.path.join(root, "profiles", "hbm_traffic.json")))
     conv = [k for k in table if k.startswith("conv_dma_kernel") or k.startswith("conv_igemm_kernel")]
