@@ -9,6 +9,7 @@
 //   wrapper (a5)          e2v/e2v_model.py:144-196
 #include "../../include/cistaflow.h"
 #include "cf_kernels.h"
+#include "fork_join.h"
 
 #include <cmath>
 #include <cstdio>
@@ -101,9 +102,15 @@ struct cf_handle {
         double* partial = nullptr;
     } enc[3];
     // library-owned side streams, forked from / joined to the caller's stream with events
-    hipStream_t aux[3] = {nullptr, nullptr, nullptr};   // library-owned side streams
-    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_upf = nullptr, ev_up = nullptr;   // intermediate up-sampling on side stream 1 (fork / done)
+    // library-owned side streams + their fork / join events, behind a checked table (fork_join.h): side 0 / 1 = encoder / flow-branch /
+    // further CISTA chains, side 2 = work nobody waits for inside the step (flow_preds up-sampling) / fourth CISTA chain
+    struct HipFJ {
+        typedef hipStream_t stream_t;
+        typedef hipEvent_t event_t;
+        bool record(hipEvent_t e, hipStream_t s) { return hipEventRecord(e, s) == hipSuccess; }
+        bool wait(hipStream_t s, hipEvent_t e) { return hipStreamWaitEvent(s, e, 0) == hipSuccess; }
+    };
+    ForkJoin<HipFJ> fj;
     float *fpair = nullptr, *fmap1 = nullptr, *emap = nullptr, *fcat = nullptr, *pfmap2 = nullptr, *net = nullptr, *inp = nullptr;
     // ERAFT: the driver's in0 of step t is its in1 of step t-1 (test_with_flow.py:144-149), so fnet(in0) is the feature
     // map the previous step left in pfmap2.  cf_hint_prev_grid() arms the reuse for the next cf_step / cf_flow_forward.
@@ -166,6 +173,11 @@ struct cf_handle {
     }
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> prof_pool;
+    // cf_plan_enable: every convolution launch records the descriptor fields the launcher's tile choice depends on + the tile it took
+    // (deduplicated); cf_plan_json hands them out.  tools/gen_kernel_table.py commits them per BASELINE config, and the CPU test
+    // replays each descriptor through cf_conv_plan (the same chooser, nothing launched) and compares: a heuristic change is a visible diff
+    bool plan_on = false;
+    std::vector<std::string> plan_rows;
     hipEvent_t prof_event() {
         if (!prof_pool.empty()) { hipEvent_t e = prof_pool.back(); prof_pool.pop_back(); return e; }
         hipEvent_t e = nullptr;
@@ -204,6 +216,15 @@ static void graph_clear(cf_handle* h);
                                              std::to_string(__LINE__));                              \
     } while (0)
 
+// fork / join bookkeeping errors (fork_join.h) become CF_ERR_STATE (CF_ERR_HIP for a failed event call) with the table's message
+#define CF_FJ(h, expr)                                                                                        \
+    do {                                                                                                      \
+        const int _f = (expr);                                                                                \
+        if (_f != FJ_OK)                                                                                      \
+            return (h)->fail(_f == FJ_BACKEND ? CF_ERR_HIP : CF_ERR_STATE,                                    \
+                             std::string(#expr) + ": " + (h)->fj.last_error + " @" + std::to_string(__LINE__)); \
+    } while (0)
+
 // every convolution of the graphs goes through here (optional HIP-event bracketing)
 #define TAG(h, t) ((h)->tag = (t))
 // tuning hook: CF_TILE_OVERRIDE="cista.P=23,gru.zr1=20" forces a tile kind for the named layers (tools only)
@@ -227,6 +248,33 @@ static int tile_override(const char* tag) {
     if (m->empty() || !tag) return 0;
     auto it = m->find(tag);
     return it == m->end() ? 0 : it->second;
+}
+
+// ---- kernel-selection plan: the integer fields of a ConvParams that launch_conv's choice can depend on, in a fixed order ----
+static const char* const PLAN_FIELDS[] = {"batch", "tile_batch", "tile_req", "a_mode", "nseg", "seg_c0", "seg_c1", "seg_c2", "seg_ld0", "seg_ld1",
+                                          "seg_ld2", "Hin", "Win", "Hsrc", "Wsrc", "Ho", "Wo", "KH", "KW", "stride", "padT", "padL", "pad_mode",
+                                          "g_cin", "g_offy", "g_offx", "cout", "cin_pad", "Ktot", "w_rows", "epi", "split", "prec", "w_div",
+                                          "per_image_w", "has_bias_groups", "has_wino", "has_wino4", "has_wino16", "has_w16", "has_stats", "has_addend",
+                                          "has_aux0", "has_out2", "out_cs", "out_ld", "has_lam"};
+static constexpr int PLAN_N = (int)(sizeof(PLAN_FIELDS) / sizeof(PLAN_FIELDS[0]));
+static void plan_fill(const ConvParams& p, int batch, int tile_req, int (&v)[PLAN_N]) {
+    const int f[PLAN_N] = {batch, p.tile_batch, tile_req, p.a_mode, p.nseg, p.seg_c[0], p.nseg > 1 ? p.seg_c[1] : 0, p.nseg > 2 ? p.seg_c[2] : 0,
+                           p.seg_ld[0], p.nseg > 1 ? p.seg_ld[1] : 0, p.nseg > 2 ? p.seg_ld[2] : 0, p.Hin, p.Win, p.Hsrc, p.Wsrc, p.Ho, p.Wo, p.KH, p.KW,
+                           p.stride, p.padT, p.padL, p.pad_mode, p.g_cin, p.g_offy, p.g_offx, p.cout, p.cin_pad, p.Ktot, p.w_rows, p.epi, p.split, p.prec,
+                           p.w_div, p.w_bs != 0 ? 1 : 0, p.bias_gs != 0 ? 1 : 0, p.w_wino ? 1 : 0, p.w_wino4 ? 1 : 0, p.w_wino16 ? 1 : 0, p.w16 ? 1 : 0,
+                           p.st_partial ? 1 : 0, p.addend ? 1 : 0, p.aux0 ? 1 : 0, p.out2 ? 1 : 0, p.out_cs, p.out_ld, p.lam ? 1 : 0};
+    for (int i = 0; i < PLAN_N; ++i) v[i] = f[i];
+}
+static void plan_record(cf_handle* h, const ConvParams& p, int batch, int tile_req, int tile_used) {
+    int v[PLAN_N];
+    plan_fill(p, batch, tile_req, v);
+    std::string row = std::string("{\"tag\":\"") + (p.tag ? p.tag : h->tag) + "\",\"tile\":" + std::to_string(tile_used) + ",\"kernel\":\"" +
+                      conv_tile_name(tile_used) + "\",\"desc\":[";
+    for (int i = 0; i < PLAN_N; ++i) row += (i ? "," : "") + std::to_string(v[i]);
+    row += "]}";
+    for (const auto& r : h->plan_rows)
+        if (r == row) return;
+    h->plan_rows.push_back(row);
 }
 
 static hipError_t run_conv(cf_handle* h, const ConvParams& p_in, int batch, hipStream_t st, int tile = 0) {
@@ -261,7 +309,11 @@ static hipError_t run_conv(cf_handle* h, const ConvParams& p_in, int batch, hipS
         p.w_div = batch / (-p.w_div);
     }
     if (!h) return launch_conv(p, batch, st, tile);
-    if (!h->prof) return launch_conv(p, batch, st, tile, &h->last_tile);
+    if (!h->prof) {
+        const hipError_t e0 = launch_conv(p, batch, st, tile, &h->last_tile);
+        if (h->plan_on && e0 == hipSuccess) plan_record(h, p, batch, tile, h->last_tile);
+        return e0;
+    }
     cf_handle::ProfRec r;
     r.a = h->prof_event();
     r.b = h->prof_event();
@@ -330,10 +382,7 @@ struct JoinGuard {
     void disarm() { armed = false; }      // normal exit: the graph has already joined what it forked
     ~JoinGuard() {
         if (!armed) return;
-        for (int i = 0; i < 3; ++i) {
-            if (!h->aux[i] || h->aux[i] == st) continue;
-            if (hipEventRecord(h->ev_join[i], h->aux[i]) == hipSuccess) (void)hipStreamWaitEvent(st, h->ev_join[i], 0);
-        }
+        h->fj.join_all(st);
         (void)hipGetLastError();
     }
 };
@@ -908,15 +957,13 @@ extern "C" int cf_create(cf_handle** out, const cf_config* cfg) {
         h->phases = atoi(e) != 0;
         for (int i = 0; h->phases && i < 4; ++i) ok = ok && hipEventCreate(&h->ph_ev[i]) == hipSuccess;
     }
-    for (int i = 0; i < 3; ++i) {
-        // aux[0], aux[1]: encoder / flow-branch / second CISTA chain; aux[2]: work nobody waits for inside the step
-        // (flow_preds up-sampling).  A low stream priority for aux[2] was measured: no effect.
-        ok = ok && hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < h->fj.MAX_SIDE; ++i) {
+        // side 0, 1: encoder / flow-branch / second CISTA chain; side 2: work nobody waits for inside the step
+        // (flow_preds up-sampling).  A low stream priority for side 2 was measured: no effect.
+        ok = ok && hipStreamCreateWithFlags(&h->fj.side[i], hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&h->fj.ev_fork[i], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&h->fj.ev_join[i], hipEventDisableTiming) == hipSuccess;
     }
-    ok = ok && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&h->ev_upf, hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&h->gstream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&h->ev_g[0], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&h->ev_g[1], hipEventDisableTiming) == hipSuccess;
@@ -954,13 +1001,11 @@ extern "C" void cf_destroy(cf_handle* h) {
     for (int i = 0; i < 2; ++i) if (h->ev_g[i]) (void)hipEventDestroy(h->ev_g[i]);
     for (void* p : h->owned) (void)hipFree(p);
     if (h->arena_mem) (void)hipFree(h->arena_mem);
-    for (int i = 0; i < 3; ++i) {
-        if (h->aux[i]) { (void)hipStreamSynchronize(h->aux[i]); (void)hipStreamDestroy(h->aux[i]); }
-        if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
+    for (int i = 0; i < h->fj.MAX_SIDE; ++i) {
+        if (h->fj.side[i]) { (void)hipStreamSynchronize(h->fj.side[i]); (void)hipStreamDestroy(h->fj.side[i]); }
+        if (h->fj.ev_fork[i]) (void)hipEventDestroy(h->fj.ev_fork[i]);
+        if (h->fj.ev_join[i]) (void)hipEventDestroy(h->fj.ev_join[i]);
     }
-    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-    if (h->ev_upf) (void)hipEventDestroy(h->ev_upf);
-    if (h->ev_up) (void)hipEventDestroy(h->ev_up);
     if (h->phases) {
         h->phase_collect();
         if (h->ph_n > 0)
@@ -1039,6 +1084,65 @@ extern "C" const char* cf_profile_report(const cf_handle* h) { return h ? h->pro
 // tile's kernel: 4/9 Winograd F(2x2,3x3), 0.6 F(2,5), 0.25 F(4x4,3x3), 1 direct)}]
 extern "C" const char* cf_profile_report_json(const cf_handle* h) { return h ? h->prof_json.c_str() : "[]"; }
 
+extern "C" int cf_plan_enable(cf_handle* h, int on) {
+    if (!h) return CF_ERR_ARG;
+    h->plan_on = on != 0;
+    if (on) h->plan_rows.clear();
+    return CF_OK;
+}
+// {"fields": [...names of desc entries...], "rows": [{tag, tile, kernel, desc: [...]}, ...]} of the launches since cf_plan_enable(h, 1)
+extern "C" const char* cf_plan_json(cf_handle* h) {
+    if (!h) return "{}";
+    std::string s = "{\"fields\":[";
+    for (int i = 0; i < PLAN_N; ++i) s += std::string(i ? "," : "") + "\"" + PLAN_FIELDS[i] + "\"";
+    s += "],\"rows\":[";
+    for (size_t i = 0; i < h->plan_rows.size(); ++i) s += (i ? "," : "") + h->plan_rows[i];
+    s += "]}";
+    h->prof_report = s;        // (storage that outlives the call; the profile report is rebuilt by every cf_profile_read)
+    return h->prof_report.c_str();
+}
+// The launcher's tile choice for one descriptor (desc: cf_plan_json's `fields` order, n entries), nothing launched, no GPU needed:
+// returns CF_OK and the tile kind launch_conv would take, or CF_ERR_ARG where it would reject the descriptor.
+extern "C" int cf_conv_plan(const int* desc, int n, int* tile_out) {
+    if (!desc || !tile_out || n != PLAN_N) return CF_ERR_ARG;
+    ConvParams p = base_params();
+    float* const fake = reinterpret_cast<float*>(static_cast<uintptr_t>(0x10000));      // aligned, never dereferenced (dry run)
+    int i = 0;
+    const int batch = desc[i++];
+    p.tile_batch = desc[i++];
+    const int tile_req = desc[i++];
+    p.a_mode = desc[i++];
+    p.nseg = desc[i++];
+    if (p.nseg < 1 || p.nseg > 3) return CF_ERR_ARG;
+    for (int k = 0; k < 3; ++k) p.seg_c[k] = desc[i++];
+    for (int k = 0; k < 3; ++k) p.seg_ld[k] = desc[i++];
+    for (int k = 0; k < p.nseg; ++k) { p.in[k] = fake; p.seg_bs[k] = 0; }
+    p.Hin = desc[i++]; p.Win = desc[i++]; p.Hsrc = desc[i++]; p.Wsrc = desc[i++]; p.Ho = desc[i++]; p.Wo = desc[i++];
+    p.KH = desc[i++]; p.KW = desc[i++]; p.stride = desc[i++]; p.padT = desc[i++]; p.padL = desc[i++]; p.pad_mode = desc[i++];
+    p.g_cin = desc[i++]; p.g_offy = desc[i++]; p.g_offx = desc[i++];
+    p.cout = desc[i++]; p.cin_pad = desc[i++]; p.Ktot = desc[i++]; p.w_rows = desc[i++]; p.epi = desc[i++]; p.split = desc[i++];
+    p.prec = desc[i++]; p.w_div = desc[i++];
+    p.w = fake;
+    p.w_bs = desc[i++] ? 1024 : 0;
+    p.bias_gs = desc[i++] ? 1024 : 0;
+    p.w_wino = desc[i++] ? fake : nullptr;
+    p.w_wino4 = desc[i++] ? fake : nullptr;
+    p.w_wino16 = desc[i++] ? fake : nullptr;
+    p.w16 = desc[i++] ? fake : nullptr;
+    p.st_partial = desc[i++] ? reinterpret_cast<double*>(fake) : nullptr;
+    p.addend = desc[i++] ? fake : nullptr;
+    p.aux0 = desc[i++] ? fake : nullptr;
+    p.out2 = desc[i++] ? fake : nullptr;
+    p.out_cs = desc[i++]; p.out_ld = desc[i++];
+    p.lam = desc[i++] ? fake : nullptr;
+    p.out = fake;
+    p.aux0_ld = p.aux0 ? 4 : 0; p.out2_ld = p.out2 ? 4 : 0; p.addend_ld = p.addend ? 4 : 0;
+    int tile = 0;
+    const hipError_t e = launch_conv(p, batch, nullptr, tile_req, &tile, true);
+    if (e != hipSuccess) return CF_ERR_ARG;
+    *tile_out = tile;
+    return CF_OK;
+}
 extern "C" const char* cf_conv_tile_name(int tile) { return conv_tile_name(tile); }
 extern "C" double cf_conv_tile_mfma_ratio(int tile) { return conv_tile_mfma_ratio(tile); }
 
@@ -1095,11 +1199,12 @@ static int cista_forward(cf_handle* h, const float* ev, const float* img, const 
         return cista_chain(h, ev, img, c_prev, z_prev, h_prev, cc_prev, I_out, c_out, z_out, h_out, cc_out, st);
     // measurement mode keeps the part-batch launches (same grids as the timed step) but issues the chains back to
     // back on the caller's stream, so that every launch runs alone on the chip
-    hipStream_t cs[4] = {st, h->serial ? st : h->aux[0], h->serial ? st : h->aux[1], h->serial ? st : h->aux[2]};
+    h->fj.folded = h->serial;
+    hipStream_t cs[4] = {st, st, st, st};
     JoinGuard jg(h, st);
-    if (!h->serial) {
-        CF_HIP(h, hipEventRecord(h->ev_fork, st));
-        for (int g = 1; g < nch; ++g) CF_HIP(h, hipStreamWaitEvent(cs[g], h->ev_fork, 0));
+    for (int g = 1; g < nch; ++g) {
+        CF_FJ(h, h->fj.stream_of(g - 1, st, &cs[g]));
+        CF_FJ(h, h->fj.fork(st, g - 1));
     }
     int rc = CF_OK;
     for (int g = 0; g < nch && rc == CF_OK; ++g) {
@@ -1110,12 +1215,7 @@ static int cista_forward(cf_handle* h, const float* ev, const float* img, const 
     h->win_b0 = 0;
     h->win_n = 0;
     if (rc != CF_OK) return rc;
-    if (!h->serial) {
-        for (int g = 1; g < nch; ++g) {
-            CF_HIP(h, hipEventRecord(h->ev_join[g - 1], cs[g]));
-            CF_HIP(h, hipStreamWaitEvent(st, h->ev_join[g - 1], 0));
-        }
-    }
+    for (int g = 1; g < nch; ++g) CF_FJ(h, h->fj.join(st, g - 1));
     jg.disarm();
     return CF_OK;
 }
@@ -1392,15 +1492,16 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
     int rc;
     // side streams; in measurement mode (cf_profile_enable) everything is serialised on the caller's stream so
     // that every kernel's HIP-event duration is that kernel alone on the chip
-    hipStream_t sx0 = h->serial ? st : h->aux[0];
-    hipStream_t sx1 = h->serial ? st : h->aux[1];
+    h->fj.folded = h->serial;
+    hipStream_t sx0 = st, sx1 = st;
+    CF_FJ(h, h->fj.stream_of(0, st, &sx0));
+    CF_FJ(h, h->fj.stream_of(1, st, &sx1));
     JoinGuard jg(h, st);
     // encoders: emap = enet(pad(ev)); fmap1 = fnet(pad(2*I-1)); cnet(pad(2*I-1)) -> net, inp.
     // The three encoders are independent and individually too small to fill 256 CUs at 1/4 and 1/8
     // resolution, so they run concurrently: enet on the caller's stream, fnet / cnet on the side streams.
-    CF_HIP(h, hipEventRecord(h->ev_fork, st));
-    CF_HIP(h, hipStreamWaitEvent(sx0, h->ev_fork, 0));
-    CF_HIP(h, hipStreamWaitEvent(sx1, h->ev_fork, 0));
+    CF_FJ(h, h->fj.fork(st, 0));
+    CF_FJ(h, h->fj.fork(st, 1));
     // Three encoders per frame.  fnet and enet (eiflow) / fnet on both voxel grids (eraft) have identical layer shapes and
     // their weights are packed as matrices 0 / 1 of grouped PackedConvs, so they can run either as ONE batch of 2B images
     // (CF_ENC_PAIR=1: per-kernel efficiency +12...50 %, 38 launches fewer) or as two chains on two streams (default:
@@ -1437,8 +1538,8 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
         ConvParams g = nhwc_conv(h->conv[pass == 0 ? "gru.pre1" : "gru.pre2"], {{h->inp, 128, 128, N * 128}}, h8, w8, h8, w8, 1, pT, pL, 0, h->gpre[pass], 384, N * 384, EPI_NONE);
         CF_HIP(h, run_conv(h, g, B, sx1));
     }
-    CF_HIP(h, hipEventRecord(h->ev_join[0], sx0));
-    CF_HIP(h, hipEventRecord(h->ev_join[1], sx1));
+    CF_FJ(h, h->fj.done(st, 0));
+    CF_FJ(h, h->fj.done(st, 1));
     // emap-only consumers overlap with the tail of fnet / cnet (with_event_updater.py:105-106 is
     // iteration-invariant)
     if (!eraft) {
@@ -1451,8 +1552,8 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
         ConvParams mp = nhwc_conv(h->conv["menc.pre"], {{h->mcat + 192, 64, 320, N * 320}}, h8, w8, h8, w8, 1, 1, 1, 0, h->mpre, 128, N * 128, EPI_NONE);
         CF_HIP(h, run_conv(h, mp, B, st));
     }
-    CF_HIP(h, hipStreamWaitEvent(st, h->ev_join[0], 0));
-    CF_HIP(h, hipStreamWaitEvent(st, h->ev_join[1], 0));
+    CF_FJ(h, h->fj.await(st, 0));
+    CF_FJ(h, h->fj.await(st, 1));
     // EIFusion  DCEIFlow.py:39-44
     if (!eraft) {
         ConvParams a = nhwc_conv(h->conv["fusion.conv1"], {{h->fmap1, 256, 256, N * 256}}, h8, w8, h8, w8, 1, 0, 0, 0, h->fcat, 384, N * 384, EPI_RELU);
@@ -1524,20 +1625,19 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
         if (it == 0) CF_HIP(h, fh_lookup(false, true));
         // BasicMotionEncoder  with_event_updater.py:102-112.  The flow branch (convf1 -> convf2) only needs
         // coords1, so it runs on a side stream next to lookup -> convc1 -> convc2.
-        CF_HIP(h, hipEventRecord(h->ev_fork, st));
-        CF_HIP(h, hipStreamWaitEvent(sx0, h->ev_fork, 0));
+        CF_FJ(h, h->fj.fork(st, 0));
         {
             ConvParams f1 = gather_conv(h->conv["convf1"], h->coords1, 2, h8, w8, 0, 0, 1.f, 0.f, 1, h8, w8, 1, 3, 3, 0, h->f1buf, 128, N * 128, EPI_RELU);
             CF_HIP(h, run_conv(h, f1, B, sx0));
             ConvParams f2 = nhwc_conv(h->conv["convf2"], {{h->f1buf, 128, 128, N * 128}}, h8, w8, h8, w8, 1, 1, 1, 0, h->mcat + FLO, MC, N * MC, EPI_RELU);
             CF_HIP(h, run_conv(h, f2, B, sx0));
-            CF_HIP(h, hipEventRecord(h->ev_join[0], sx0));
+            CF_FJ(h, h->fj.done(st, 0));
         }
         ConvParams c1 = nhwc_conv(h->conv["convc1"], {{h->corrfeat, cf_handle::CORR_LD, cf_handle::CORR_LD, N * cf_handle::CORR_LD}}, h8, w8, h8, w8, 1, 0, 0, 0, h->c1buf, 256, N * 256, EPI_RELU);
         CF_HIP(h, run_conv(h, c1, B, st));
         ConvParams c2 = nhwc_conv(h->conv["convc2"], {{h->c1buf, 256, 256, N * 256}}, h8, w8, h8, w8, 1, 1, 1, 0, h->mcat, MC, N * MC, EPI_RELU);
         CF_HIP(h, run_conv(h, c2, B, st));
-        CF_HIP(h, hipStreamWaitEvent(st, h->ev_join[0], 0));
+        CF_FJ(h, h->fj.await(st, 0));
         ConvParams mc = eraft ? nhwc_conv(h->conv["menc.conv"], {{h->mcat, MC, MC, N * MC}}, h8, w8, h8, w8, 1, 1, 1, 0, h->motion, 128, N * 128, EPI_RELU)
                               : nhwc_conv(h->conv["menc.conv"], {{h->mcat, 192, MC, N * MC}, {h->mcat + FLO, 64, MC, N * MC}}, h8, w8, h8, w8, 1, 1, 1, 0,
                                           h->motion, 128, N * 128, EPI_RELU);
@@ -1560,7 +1660,7 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
             set_out2(a, h->rh, 128, N * 128);
             CF_HIP(h, run_conv(h, a, B, st));
             if (up_pending) {      // q writes net in place
-                CF_HIP(h, hipStreamWaitEvent(st, h->ev_up, 0));
+                CF_FJ(h, h->fj.await(st, 2));
                 up_pending = false;
             }
             ConvParams q = nhwc_conv(qq, {{h->rh, 128, 128, N * 128}, {h->motion, 128, 128, N * 128}}, h8, w8, h8, w8, 1, pT, pL, 0, h->net, 128, N * 128, EPI_GRU_Q);
@@ -1579,9 +1679,8 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
         float* up = flow_preds ? flow_preds + (long)it * B * 2 * h->Hp * h->Wp : nullptr;
         hipStream_t su = st;
         if (!last && up && !h->serial) {
-            su = h->aux[2];
-            CF_HIP(h, hipEventRecord(h->ev_upf, st));
-            CF_HIP(h, hipStreamWaitEvent(su, h->ev_upf, 0));
+            CF_FJ(h, h->fj.stream_of(2, st, &su));
+            CF_FJ(h, h->fj.fork(st, 2));
         }
         if (!eraft) {
             // upflow8 + unpad   DCEIFlow.py:222-227
@@ -1603,11 +1702,11 @@ static int eiflow_forward(cf_handle* h, const float* ev, const float* img, const
                                                h->W, h->padH, h->padW, last ? flag : nullptr, nullptr, nullptr, su)); }
         }
         if (su != st) {
-            CF_HIP(h, hipEventRecord(h->ev_up, su));
+            CF_FJ(h, h->fj.done(st, 2));
             up_pending = true;
         }
     }
-    if (up_pending) CF_HIP(h, hipStreamWaitEvent(st, h->ev_up, 0));
+    if (up_pending) CF_FJ(h, h->fj.await(st, 2));
     if (flow_low && !low_done) {
         // flow_init of the returned dict = coords1 - coords0 at 1/8 resolution (DCEIFlow.py:297); DCEIFlow folds it into the last
         // iteration's upflow8 launch
@@ -1776,6 +1875,12 @@ static int step_body(cf_handle* h, const StepArgs& a, bool reuse, hipStream_t st
     const float* ev_now = h->cfg.mode == CF_MODE_ERAFT ? a.in1 : a.in0;
     rc = cista_forward(h, ev_now, h->warpedI, a.c_prev, zin, a.h_prev, a.cc_prev, a.I_out, a.c_out, a.z_out, a.h_out, a.cc_out, st);
     h->phase_mark(3, st);
+    // every side stream the step forked has been joined back (under capture an un-joined one would poison hipStreamEndCapture; in
+    // eager mode it would still be running when the caller frees its tensors)
+    if (rc == CF_OK && !h->fj.all_idle()) {
+        h->fj.join_all(st);
+        return h->fail(CF_ERR_STATE, "cf_step: a side stream was left un-joined");
+    }
     return rc;
 }
 
@@ -1857,6 +1962,10 @@ static int step_dispatch(cf_handle* h, const StepArgs& a, bool reuse, hipStream_
             return step_body(h, a, reuse, st);
         }
         rc = step_body(h, a, reuse, run);
+        if (!h->fj.all_idle()) {                   // (an error path's JoinGuard has already joined: this is the belt to its braces)
+            h->fj.join_all(run);
+            if (rc == CF_OK) rc = h->fail(CF_ERR_STATE, "cf_step: capture ended with an un-joined side stream");
+        }
         hipGraph_t graph = nullptr;
         const hipError_t ee = hipStreamEndCapture(run, &graph);
         if (rc != CF_OK || ee != hipSuccess || !graph) {
@@ -2111,6 +2220,10 @@ extern "C" int cf_quantize_u8(const float* img, unsigned char* out, long long n,
 }
 
 // f-3: evaluation metrics on the device (metrics.hip); stateless, asynchronous, results stay on the device
+extern "C" int cf_flow_to_bgr(const float* flow, int B, int H, int W, unsigned char* out, unsigned int* scratch, void* stream) {
+    return launch_flow_to_bgr(flow, B, H, W, out, scratch, static_cast<hipStream_t>(stream)) == hipSuccess ? CF_OK : CF_ERR_HIP;
+}
+
 extern "C" size_t cf_metrics_scratch_doubles(void) { return (size_t)metrics_scratch_doubles(); }
 extern "C" int cf_metrics_recon(const float* rec, const float* target, long long n, double* out2, double* scratch, void* stream) {
     if (!rec || !target || !out2 || !scratch || n <= 0) return CF_ERR_ARG;

@@ -117,7 +117,7 @@ struct ConvParams {
 };
 
 // tile: 0 auto, else explicit (see conv_igemm.hip); tile_used (nullable) returns the choice
-hipError_t launch_conv(const ConvParams& p, int batch, hipStream_t s, int tile = 0, int* tile_used = nullptr);
+hipError_t launch_conv(const ConvParams& p, int batch, hipStream_t s, int tile = 0, int* tile_used = nullptr, bool dry = false);
 const char* conv_tile_name(int tile);
 double conv_tile_mfma_ratio(int tile);      // executed / algorithmic flops of that tile's kernel (Winograd forms < 1)
 // U = G g G^T of a packed 3x3 matrix [rows][9][cin_pad] in conv_wino_kernel's block layout (wino_weight_floats floats)
@@ -280,6 +280,9 @@ hipError_t launch_upsample2x_nhwc(const float* src, int s_ld, long s_bs, float* 
 
 // f-2: np.uint8(pred * 255.) of the reconstructed frames (test_with_flow.py:174)
 hipError_t launch_quantize_u8(const float* x, unsigned char* out, long n, hipStream_t s);
+// f-2: FlowWriter's colour coding (utils/data_io.py:9-29): flow [B][2][H][W] -> BGR uint8 [B][H][W][3]; scratch: B unsigned ints.
+// UNPINNED by the reference (cv2 absent): OpenCV's published 8-bit HSV -> BGR arithmetic, see pointwise.hip
+hipError_t launch_flow_to_bgr(const float* flow, int B, int H, int W, unsigned char* out, unsigned* scratch, hipStream_t s);
 
 // f-3: evaluation metrics on the device (metrics.hip).  out / scratch are device doubles; scratch holds
 // metrics_scratch_doubles() entries.  All asynchronous on `s`, deterministic (fixed-order fp64 folds).

@@ -1762,7 +1762,9 @@ static int default_dma() {
     return v;
 }
 
-hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int tile, int* tile_used) {
+// dry: validate the descriptor and CHOOSE the tile exactly as a real launch would (tile_used, g_last_launch.kernel), but put nothing on
+// the stream -- what cf_conv_plan and tests/test_kernel_selection_cpu.py use to pin the launcher's heuristics without a GPU
+hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int tile, int* tile_used, bool dry) {
     ConvParams p = p_in;
 #if defined(CF_STAMP) || defined(CF_CENSUS)
     { const char* e = getenv("CF_STAMP_BUF"); p.stamp = e ? reinterpret_cast<long long*>(strtoull(e, nullptr, 10)) : nullptr; }
@@ -1831,6 +1833,7 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
     if (tile == 7 || tile == 15) {
         if (!smalln_ok(p)) return hipErrorInvalidValue;
         if (tile_used) *tile_used = 7;
+        if (dry) { g_last_launch.kernel = conv_tile_name(7); return hipSuccess; }
         return launch_smalln(p, batch, s, tile == 15);
     }
     // 3x3 / stride 1 layers whose caller supplied the transformed weights run as Winograd F(2x2,3x3): 1.2-1.55x the direct
@@ -1948,6 +1951,7 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
     if (tile_used) *tile_used = tile;
     g_last_launch.kernel = conv_tile_name(tile);
     if (p.prec != 0 && p.prec != 1 && p.prec != 3) return hipErrorInvalidValue;
+    if (dry) return hipSuccess;
     if (p.prec != 0) {          // f16 modes: pre-split weights when there are some, else split B while staging
         if (p.w16 && (p.w_bs == 0 || p.w_div > 1)) {
             p.w = static_cast<const float*>(p.w16);

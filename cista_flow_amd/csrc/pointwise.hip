@@ -1232,6 +1232,70 @@ __global__ __launch_bounds__(256) void quantize_u8_kernel(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------
+// f-2 output stage: flow -> HSV -> BGR colour coding of FlowWriter (utils/data_io.py:9-29, merge_optical_flow):
+//     magnitude, angle = cv2.cartToPolar(u, v); H = uint8(angle * 180 / pi / 2); S = 255; V = uint8(255 * magnitude / magnitude.max());
+//     bgr = cv2.cvtColor(hsv, cv2.COLOR_HSV2BGR)
+// UNPINNED: cv2 is not installed in the build container, so no reference-run vector exists.  What is restated is OpenCV's PUBLISHED
+// arithmetic: cartToPolar's angle in [0, 2 pi) (here atan2f, OpenCV uses a polynomial of ~0.01 degree accuracy: a pixel whose hue sits on an
+// integer boundary can land in the neighbouring 2-degree bucket), the truncating uint8 casts numpy does, and the 8-bit HSV -> BGR of
+// cvtColor: h6 = H / 30 (hue range 180), sector = floor(h6), f = h6 - sector, tab = {v, v (1 - s), v (1 - s f), v (1 - s (1 - f))} with s, v
+// in [0, 1], channel = round-half-even(255 * tab[sector table]).  One image = one maximum: pass 1 folds max |flow| per image with an
+// integer atomicMax on the float's bits (magnitudes are >= 0, so the orders agree; deterministic), pass 2 colours.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void flow_maxmag_kernel(const float* __restrict__ flow, long HW, unsigned* __restrict__ maxbits) {
+    const int b = blockIdx.y;
+    const float* u = flow + (long)b * 2 * HW;
+    const float* v = u + HW;
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (long)gridDim.x * blockDim.x) m = fmaxf(m, sqrtf(u[i] * u[i] + v[i] * v[i]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(maxbits + b, __float_as_uint(m));
+}
+
+__global__ __launch_bounds__(256) void flow_to_bgr_kernel(const float* __restrict__ flow, long HW, const unsigned* __restrict__ maxbits,
+                                                          unsigned char* __restrict__ out) {
+    const int b = blockIdx.y;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HW) return;
+    const float u = flow[(long)b * 2 * HW + i], v = flow[(long)b * 2 * HW + HW + i];
+    const float mag = sqrtf(u * u + v * v);
+    float ang = atan2f(v, u);
+    if (ang < 0.f) ang += 6.283185307179586f;
+    const float mx = __uint_as_float(maxbits[b]);
+    // numpy: float32 arithmetic, then the C cast of the uint8 assignment (truncation); an all-zero flow gives 0 / 0 = NaN -> 0 here
+    const int H = (int)(ang * 180.f / 3.14159265358979323846f / 2.f) & 255;
+    const int V = mx > 0.f ? (int)(255.f * mag / mx) : 0;
+    const float vv = (float)V * (1.f / 255.f);
+    float h6 = (float)H * (6.f / 180.f);
+    int sector = (int)floorf(h6);
+    const float f = h6 - (float)sector;
+    sector = sector % 6;                       // H < 180 after the cast above unless the angle rounds to 2 pi: hue 180 = sector 6 = sector 0
+    const float tab[4] = {vv, 0.f, vv * (1.f - f), vv * f};       // s = 1
+    const int sd[6][3] = {{1, 3, 0}, {1, 0, 2}, {3, 0, 1}, {0, 2, 1}, {0, 1, 3}, {2, 1, 0}};      // (b, g, r) per sector
+    unsigned char* o = out + ((long)b * HW + i) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float t = tab[sd[sector][c]] * 255.f;
+        t = fminf(fmaxf(t, 0.f), 255.f);
+        o[c] = (unsigned char)__float2int_rn(t);
+    }
+}
+
+hipError_t launch_flow_to_bgr(const float* flow, int B, int H, int W, unsigned char* out, unsigned* scratch, hipStream_t s) {
+    if (!flow || !out || !scratch || B <= 0 || H <= 0 || W <= 0) return hipErrorInvalidValue;
+    const long HW = (long)H * W;
+    hipError_t e = hipMemsetAsync(scratch, 0, sizeof(unsigned) * (size_t)B, s);
+    if (e != hipSuccess) return e;
+    const unsigned nb = (unsigned)((HW + 255) / 256);
+    note_launch("flow_maxmag_kernel", dim3(nb < 64 ? nb : 64, (unsigned)B), dim3(256));
+    hipLaunchKernelGGL(flow_maxmag_kernel, dim3(nb < 64 ? nb : 64, (unsigned)B), dim3(256), 0, s, flow, HW, scratch);
+    note_launch("flow_to_bgr_kernel", dim3(nb, (unsigned)B), dim3(256));
+    hipLaunchKernelGGL(flow_to_bgr_kernel, dim3(nb, (unsigned)B), dim3(256), 0, s, flow, HW, scratch, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_quantize_u8(const float* x, unsigned char* out, long n, hipStream_t s) {
     if (!x || !out || n <= 0) return hipErrorInvalidValue;
     const long threads = (n + 3) / 4;

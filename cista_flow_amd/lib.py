@@ -22,7 +22,7 @@ SYMBOLS = [
     "cf_op_nhwc_to_nchw", "cf_profile_enable", "cf_profile_read", "cf_conv_tile_name", "cf_profile_report", "cf_op_conv2d_bench", "cf_events_to_voxel", "cf_op_conv2d_inorm_stats", "cf_quantize_u8", "cf_hint_prev_grid",
     "cf_profile_report_json", "cf_metrics_scratch_doubles", "cf_metrics_recon", "cf_metrics_flow", "cf_metrics_fwl",
     "cf_graph_enable", "cf_graph_stats", "cf_events_to_voxel_ex", "cf_voxel_preprocess", "cf_metrics_ssim",
-    "cf_conv_tile_mfma_ratio",
+    "cf_conv_tile_mfma_ratio", "cf_plan_enable", "cf_plan_json", "cf_conv_plan", "cf_flow_to_bgr",
 ]
 
 
@@ -122,6 +122,14 @@ def load():
     lib.cf_conv_tile_name.restype = C.c_char_p
     lib.cf_conv_tile_mfma_ratio.argtypes = [i]
     lib.cf_conv_tile_mfma_ratio.restype = C.c_double
+    lib.cf_plan_enable.argtypes = [vp, i]
+    lib.cf_plan_enable.restype = i
+    lib.cf_plan_json.argtypes = [vp]
+    lib.cf_plan_json.restype = C.c_char_p
+    lib.cf_conv_plan.argtypes = [C.POINTER(C.c_int), i, C.POINTER(C.c_int)]
+    lib.cf_conv_plan.restype = i
+    lib.cf_flow_to_bgr.argtypes = [fp, i, i, i, vp, vp, vp]
+    lib.cf_flow_to_bgr.restype = i
     _lib = lib
     return lib
 
@@ -131,6 +139,17 @@ def ptr(t):
     if t is None:
         return None
     return C.c_void_p(t.data_ptr())
+
+
+def conv_plan(desc):
+    """The launcher's tile choice for one recorded descriptor (Handle.plan() row["desc"]): pure host logic, no GPU. -> (tile, kernel)"""
+    lib = load()
+    arr = (C.c_int * len(desc))(*[int(v) for v in desc])
+    tile = C.c_int(0)
+    rc = lib.cf_conv_plan(arr, len(desc), C.byref(tile))
+    if rc != 0:
+        raise RuntimeError("cf_conv_plan rejected the descriptor (%d)" % rc)
+    return tile.value, lib.cf_conv_tile_name(tile.value).decode()
 
 
 def current_stream_ptr(device=None):
@@ -201,7 +220,7 @@ class Handle:
 
     def profile_read(self):
         """-> list of dicts per conv tile kind: name, ms, flops, count (index 0 = all conv launches)."""
-        n = 48
+        n = 56
         ms, fl, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_longlong * n)()
         self.check(self.lib.cf_profile_read(self.h, ms, fl, cnt, n), "cf_profile_read")
         out = []
@@ -217,6 +236,15 @@ class Handle:
         """Rows of the last profile_read over both roofline classes: tag, kernel, grid, class, launches, ms, work."""
         import json
         return json.loads(self.lib.cf_profile_report_json(self.h).decode())
+
+    def plan_enable(self, on=True):
+        """Record, for every convolution launch from now on, the descriptor fields the tile choice depends on and the tile taken."""
+        self.check(self.lib.cf_plan_enable(self.h, 1 if on else 0), "cf_plan_enable")
+
+    def plan(self):
+        """-> {"fields": [...], "rows": [{"tag", "tile", "kernel", "desc"}, ...]} (deduplicated) since plan_enable()."""
+        import json
+        return json.loads(self.lib.cf_plan_json(self.h).decode())
 
     @property
     def workspace_bytes(self):

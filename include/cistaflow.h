@@ -144,9 +144,16 @@ int cf_voxel_preprocess(float* voxel, int B, long long voxels_per_grid, double* 
                         float hot_pixel_threshold, void* stream);
 
 /* f-2  output stage, `np.uint8(pred_image * 255.)` (test_with_flow.py:174): fp32 product, truncation toward zero,
- * on the device (img: n floats in [0,1], out: n bytes).  Stateless, asynchronous on `stream`.  The PNG encoder and the
- * flow -> HSV colour coding (utils/data_io.py:9-29, defined by cv2.cartToPolar / cvtColor) stay on the host. */
+ * on the device (img: n floats in [0,1], out: n bytes).  Stateless, asynchronous on `stream`.  The PNG encoder stays on the
+ * host (cista_flow_amd/utils/data_io.py: ImageWriter / FlowWriter on PIL); the flow colour coding is cf_flow_to_bgr below. */
 int cf_quantize_u8(const float* img, unsigned char* out, long long n, void* stream);
+/* f-2, the other half of the output stage: FlowWriter's colour coding `merge_optical_flow` (utils/data_io.py:9-29; caller
+ * test_with_flow.py:178): flow [B][2][H][W] fp32 -> BGR uint8 [B][H][W][3] (the array cv2.imwrite receives), per image
+ * H = uint8(angle * 180 / pi / 2), S = 255, V = uint8(255 * |flow| / max |flow|), then OpenCV's 8-bit HSV -> BGR.  scratch: B unsigned
+ * ints on the device.  UNPINNED by the reference: cv2 is not installed where the goldens are generated, so this follows OpenCV's
+ * published arithmetic and is tested against a numpy restatement of it (oracle.merge_optical_flow), not against cv2 itself. */
+int cf_flow_to_bgr(const float* flow, int B, int H, int W, unsigned char* out_bgr, unsigned int* scratch, void* stream);
+
 
 /* f-3  evaluation metrics on the device (loss.py of the reference).  Stateless and asynchronous on
  * `stream`; every result is written to DEVICE doubles (`out*`), so a caller reads a frame's scores with one small copy
@@ -192,6 +199,15 @@ const char* cf_conv_tile_name(int tile);
  * the rows of cf_profile_report_json carry it as "mfma_ratio" next to "tile", so the executed-MFMA roofline fraction is priced per
  * launch site from the library's own table */
 double cf_conv_tile_mfma_ratio(int tile);
+
+/* kernel-selection plan.  cf_plan_enable(h, 1): every convolution launch of the handle records (deduplicated) the integer fields of its
+ * descriptor that the launcher's tile choice can depend on + the tile it took; cf_plan_json returns
+ * {"fields": [names], "rows": [{"tag", "tile", "kernel", "desc": [ints in `fields` order]}]}.  cf_conv_plan replays ONE such descriptor
+ * through the same chooser without launching anything (no GPU needed): tests/test_kernel_selection_cpu.py holds every BASELINE config's
+ * committed table (tests/golden/kernel_selection.json, tools/gen_kernel_table.py) against it, so a launcher-heuristic change is a diff. */
+int cf_plan_enable(cf_handle* h, int on);
+const char* cf_plan_json(cf_handle* h);
+int cf_conv_plan(const int* desc, int n, int* tile_out);
 /* per-layer text table of the last cf_profile_read (layer, tile kind, launches, ms, TFLOP/s) */
 const char* cf_profile_report(const cf_handle* h);
 const char* cf_profile_report_json(const cf_handle* h);

@@ -690,3 +690,33 @@ def ssim(X, Y, data_range=1.0, win_size=11, win_sigma=1.5, K=(0.01, 0.03), dtype
     cs_map = (2 * s12 + C2) / (s1 + s2 + C2)
     ssim_map = ((2 * mu1_mu2 + C1) / (mu1_sq + mu2_sq + C1)) * cs_map
     return float(ssim_map.flatten(2).mean(-1).mean()), float(cs_map.flatten(2).mean(-1).mean())
+
+
+def merge_optical_flow(flow):
+    """FlowWriter's colour coding, utils/data_io.py:9-29, restated in numpy float32 from OpenCV's PUBLISHED arithmetic (UNPINNED: cv2 is
+    absent, so no reference-run vector exists): cartToPolar -> angle in [0, 2 pi) and magnitude; H = uint8(angle * 180 / pi / 2) and
+    V = uint8(255 * magnitude / magnitude.max()) with numpy's truncating casts, S = 255; cvtColor(HSV2BGR) for 8-bit images:
+    h6 = H / 30, sector = floor(h6), f = h6 - sector, tab = [v, v (1 - s), v (1 - s f), v (1 - s (1 - f))] with s, v in [0, 1], channels from the
+    sector table, rounded half-to-even to uint8.  flow: [2, H, W] array -> [H, W, 3] uint8 (B, G, R)."""
+    import numpy as np
+    fx = np.asarray(flow[0], dtype=np.float32)
+    fy = np.asarray(flow[1], dtype=np.float32)
+    mag = np.sqrt(fx * fx + fy * fy).astype(np.float32)
+    ang = np.arctan2(fy, fx).astype(np.float32)
+    ang = np.where(ang < 0, ang + np.float32(2 * np.pi), ang).astype(np.float32)
+    H = (ang * np.float32(180.0) / np.float32(np.pi) / np.float32(2.0)).astype(np.int32) & 255
+    mx = mag.max()
+    V = (np.float32(255.0) * mag / mx).astype(np.int32) if mx > 0 else np.zeros_like(H)
+    v = V.astype(np.float32) * np.float32(1.0 / 255.0)
+    h6 = H.astype(np.float32) * np.float32(6.0 / 180.0)
+    sector = np.floor(h6).astype(np.int32)
+    f = h6 - sector.astype(np.float32)
+    sector = sector % 6
+    tab = np.stack([v, np.zeros_like(v), v * (np.float32(1.0) - f), v * f], axis=0)        # s = 1
+    sd = np.array([[1, 3, 0], [1, 0, 2], [3, 0, 1], [0, 2, 1], [0, 1, 3], [2, 1, 0]])
+    out = np.zeros(H.shape + (3,), dtype=np.uint8)
+    yy, xx = np.indices(H.shape)
+    for c in range(3):
+        t = tab[sd[sector, c], yy, xx] * np.float32(255.0)
+        out[..., c] = np.rint(np.clip(t, 0, 255)).astype(np.uint8)
+    return out
