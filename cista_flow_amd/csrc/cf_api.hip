@@ -2098,7 +2098,7 @@ static int op_conv2d_impl(const float* in, int B, int Cin, int H, int W, const f
         p.w_wino4 = static_cast<float*>(wino4.p);
     }
     TmpBuf wino;
-    if ((tile == 40 || tile == 41 || tile == 44 || tile == 45 || tile == 48) && !gather && KH == 3 && KW == 3) {      // Winograd tile: needs the transformed weights
+    if ((tile == 40 || tile == 44 || tile == 45 || tile == 48 || tile == 49) && !gather && KH == 3 && KW == 3) {      // Winograd tile: needs the transformed weights
         if (hipMalloc(&wino.p, sizeof(float) * (size_t)wino_weight_floats(Cout, pc.cin_pad)) != hipSuccess) return CF_ERR_HIP;
         if (launch_wino_weights(pc.w, static_cast<float*>(wino.p), Cout, pc.cin_pad, st) != hipSuccess) return CF_ERR_HIP;
         p.w_wino = static_cast<float*>(wino.p);

@@ -143,13 +143,9 @@ int wino16_regions(int Ho, int Wo);
 hipError_t launch_wino16(const ConvParams& p, int batch, hipStream_t s);
 // conv_wino_p.hip, reached through launch_conv (tile 48): conv_wino_kernel's arithmetic in persistent workgroups that walk several regions
 bool wino_p_ok(const ConvParams& p);
-int wino_p_walkers(const ConvParams& p, long NR);
-hipError_t launch_wino_p(const ConvParams& p, int batch, hipStream_t s);
+int wino_p_walkers(const ConvParams& p, long NR, int pipe = 0);
+hipError_t launch_wino_p(const ConvParams& p, int batch, hipStream_t s, int pipe = 0);      // pipe = 1: tile 49, software-pipelined chunk loop
 long wino16_max();         // CF_WINO16_MAX (default 640; 0 = never take tile 47 and do not build its weights)
-// conv_patch.hip, reached through launch_conv (tile 43): planar small-Cin inputs (A_GATHER) with an LDS-resident input patch
-bool patch_ok(const ConvParams& p);
-int patch_tiles(int Ho, int Wo);
-hipError_t launch_patch(const ConvParams& p, int batch, hipStream_t s);
 extern long g_wino4_min;   // launches with at least this many F(4x4,3x3) workgroups take tile 42 (0 = never; CF_WINO4_MIN at cf_create)
 // conv_wino4.hip, reached through launch_conv (tile 42)
 bool wino4_ok(const ConvParams& p);

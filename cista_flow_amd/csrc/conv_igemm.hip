@@ -1179,213 +1179,6 @@ __global__ __launch_bounds__(256, 4) void conv_wino_kernel(const ConvParams p) {
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// The same Winograd kernel with eight waves per workgroup: 32 tiles x 64 output channels, K in chunks of 16 channels.
-// Everything that is not an MFMA (raw-patch DMA, input transform, U loads) costs SIMD issue time that the matrix pipe does
-// not hide (ablations: the costs add up), and the transform + raw patch of a region serve every output channel: with 64
-// channels per workgroup they are paid once per 32 MFMAs of a wave instead of once per 16.  Wave w = (i = w & 3, h = w >> 2)
-// owns positions (i, 0..3) of output channels [n0 + 32 h, n0 + 32 h + 32); a lane transforms one (tile, channel) of the
-// 32 x 16 chunk.  Needs cout % 64 == 0 and every channel segment % 16 == 0; the U layout is the four-wave kernel's.
-static constexpr int W8_KC = 16;
-static constexpr int W8_RAW = 768 * 4;                      // floats per raw buffer: 720 16-byte slots, padded to whole wave-instructions
-static constexpr int W8_V = 16 * 32 * W8_KC;                // floats of V (8192)
-
-__global__ __launch_bounds__(512, 4) void conv_wino8_kernel(const ConvParams p) {
-    //   sV    [16 pos][32 tiles][16 k]  (32 KB)   } after the loop: the exchange X[8 waves][2][32][32] (64 KB), then the
-    //   sRaw  [2][W8_RAW]               (24 KB)   } eight epilogue patches
-    // one __shared__ object: see conv_wino_kernel
-    constexpr int W8_A = 8 * 2 * 32 * 32;
-    static_assert(W8_V + 2 * W8_RAW <= W8_A && 8 * 32 * EPI_S <= W8_A, "loop buffers and patches overlay the exchange buffer");
-    __shared__ __attribute__((aligned(16))) float smem[W8_A + 8 * 32];
-    float* const sV = smem;
-    float* const sRaw = sV + W8_V;
-    float* const sPatch = smem;
-    int* const sMtab = reinterpret_cast<int*>(smem + W8_A);
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wi = wave & 3, wh = wave >> 2;
-    const int Ho = p.Ho, Wo = p.Wo;
-    const int tall = wino_tall(Ho, Wo);
-    const int TWr = tall ? 4 : 8;
-    const int RH = tall ? 16 : 8, RW = tall ? 8 : 16;
-    const int PC = RW + 2, PCh = PC >> 1;
-    const int nrx = (Wo + RW - 1) / RW, nry = (Ho + RH - 1) / RH;
-    const int nreg = nrx * nry;
-    const int nt = p.cout / 64;
-    int tile_id = blockIdx.x;
-    if (p.sched == 1) {
-        const int nwg = gridDim.x;
-        const int q8 = nwg >> 3, r8 = nwg & 7;
-        const int xcd = tile_id & 7;
-        tile_id = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (tile_id >> 3);
-    }
-    const int nblk = tile_id % nt;
-    const int rest = tile_id / nt;
-    const int reg = rest % nreg;
-    const int b = rest / nreg;
-    const int oy0 = (reg / nrx) * RH, ox0 = (reg % nrx) * RW;
-    const int n0 = nblk * 64 + wh * 32;
-
-    // raw patch DMA slots: slot s -> patch cell s >> 2 (even columns first, as in conv_wino_kernel), channel quad s & 3
-    int a_pix[2];
-    unsigned a_q[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int sl = tid + 512 * j;
-        const int cell = sl >> 2;
-        a_q[j] = (unsigned)(sl & 3) * 16u;
-        const int py = cell / PC, pc = cell - py * PC;
-        const int px = pc < PCh ? 2 * pc : 2 * (pc - PCh) + 1;
-        int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
-        bool ok = sl < 4 * WG_PIX && iy <= p.Hin && ix <= p.Win;
-        if (p.pad_mode == 1) {
-            iy = reflect_idx(iy, p.Hin);
-            ix = reflect_idx(ix, p.Win);
-        } else {
-            ok = ok && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
-        }
-        a_pix[j] = ok ? iy * p.Win + ix : -1;
-    }
-    const int nchunk = p.cin_pad / W8_KC;
-    const __amdgpu_buffer_rsrc_t u_rsrc =
-        make_rsrc(p.w_wino + (long)wgroup(p, b) * p.wino_gs + (long)(nblk * 2 + wh) * (p.cin_pad / WG_KC) * WG_UV);
-
-    int it_seg = 0, it_cs = 0;
-    const float* seg_base = p.in[0] + (long)b * p.seg_bs[0];
-    int seg_ld = p.seg_ld[0], seg_cn = p.seg_c[0];
-    auto issue_raw = [&](int buf) __attribute__((always_inline)) {
-        const __amdgpu_buffer_rsrc_t rs = make_rsrc(seg_base);
-        const unsigned ld4 = (unsigned)seg_ld * 4u, so = (unsigned)it_cs * 4u;
-        float* rbase = sRaw + buf * W8_RAW;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (512 * j + 64 * wave < 4 * WG_PIX) {        // wave-uniform: this wave-instruction covers live slots
-                const unsigned off = a_pix[j] < 0 ? BUF_OOB : (unsigned)a_pix[j] * ld4 + a_q[j];
-                dma16_to_lds(rs, rbase + (512 * j + 64 * wave) * 4, off, so);
-            }
-        }
-        it_cs += W8_KC;
-        if (it_cs >= seg_cn) {
-            it_cs = 0;
-            ++it_seg;
-            if (it_seg < p.nseg) {
-                seg_base = sel3(p.in, it_seg) + (long)b * (it_seg == 1 ? p.seg_bs[1] : p.seg_bs[2]);
-                seg_ld = it_seg == 1 ? p.seg_ld[1] : p.seg_ld[2];
-                seg_cn = it_seg == 1 ? p.seg_c[1] : p.seg_c[2];
-            }
-        }
-    };
-
-    f32x16 acc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-
-    // transform mapping: tile t = wave * 4 + (lane >> 4), channel lane & 15
-    const int tl4 = lane >> 4, tc = lane & 15;
-    const int tt = wave * 4 + tl4, tty = tt / TWr, ttx = tt - tty * TWr;
-    const int rsrc0 = (2 * tty * PC + ttx) * W8_KC + tc;
-    const int vdst = tt * W8_KC + ((((tc >> 2) ^ ((tt >> 2) & 3)) << 2) | (tc & 3));     // + pos * 32 * 16
-    // fragments: A = row lr of V, logical k quad 2 e + lh, stored at quad ^ ((lr >> 2) & 3) (conflict-free ds_read_b128);
-    // B = U block (8-channel chunk 2 k + e, position (wi, j)): row lr, quad lh ^ ((lr >> 3) & 1) as launch_wino_weights wrote it
-    const int lr = lane & 31, lh = lane >> 5;
-    const int fragA0 = lr * W8_KC + (((0 + lh) ^ ((lr >> 2) & 3)) << 2);
-    const int fragA1 = lr * W8_KC + (((2 + lh) ^ ((lr >> 2) & 3)) << 2);
-    const unsigned uoff0 = (unsigned)((wi * 4) * 256 + lr * WG_KC + ((lh ^ ((lr >> 3) & 1)) << 2)) * 4u;
-    const unsigned uoff1 = uoff0 + (unsigned)WG_UV * 4u;
-
-    f32x4 bu[2][4];
-    auto chunk_step = [&](int k) __attribute__((always_inline)) {
-        wait_vmcnt0();
-        raw_barrier();                              // raw(k) has landed for everybody; iteration k-1 is finished everywhere
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bu[0][j] = buf_load4(u_rsrc, uoff0 + 1024u * j, (unsigned)k * (2u * WG_UV * 4u));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bu[1][j] = buf_load4(u_rsrc, uoff1 + 1024u * j, (unsigned)k * (2u * WG_UV * 4u));
-        __builtin_amdgcn_sched_barrier(0);          // U(k) before raw(k+1) in issue order: the MFMAs then wait for U(k) only
-        if (k + 1 < nchunk) issue_raw((k + 1) & 1);
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            const float* r = sRaw + (k & 1) * W8_RAW + rsrc0;
-            float d[4][4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) d[i][j] = r[(i * PC + (j >> 1) + (j & 1) * PCh) * W8_KC];
-            float t[4][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                t[0][j] = d[0][j] - d[2][j];
-                t[1][j] = d[1][j] + d[2][j];
-                t[2][j] = d[1][j] - d[2][j];          // negated, as the stored U of row 2 is (launch_wino_weights)
-                t[3][j] = d[1][j] - d[3][j];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                sV[(i * 4 + 0) * 512 + vdst] = t[i][0] - t[i][2];
-                sV[(i * 4 + 1) * 512 + vdst] = t[i][1] + t[i][2];
-                sV[(i * 4 + 2) * 512 + vdst] = t[i][2] - t[i][1];
-                sV[(i * 4 + 3) * 512 + vdst] = t[i][1] - t[i][3];
-            }
-        }
-        wait_lgkm0();
-        raw_barrier();                              // V is complete (NOT __syncthreads: it would drain the prefetch)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            f32x4 af[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const f32x4*>(sV + (wi * 4 + j) * 512 + (e ? fragA1 : fragA0));
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][s2], bu[e][j][s2], acc[j], 0, 0, 0);
-        }
-    };
-    issue_raw(0);
-    for (int k = 0; k < nchunk; ++k) chunk_step(k);
-
-    wait_vmcnt0();                                  // the dead past-the-end DMA of the last chunk step has landed (explicit: ADVICE r3)
-    __syncthreads();                                // every wave is done with V before it becomes the exchange buffer
-    float* X = smem;                                // X[wave][bcol][tile 32][cout 32]
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int trow = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        X[((wave * 2 + 0) * 32 + trow) * 32 + lr] = (acc[0][r] + acc[1][r]) + acc[2][r];
-        X[((wave * 2 + 1) * 32 + trow) * 32 + lr] = (acc[1][r] - acc[2][r]) - acc[3][r];
-    }
-    __syncthreads();
-    float* sW = sPatch + wave * (32 * EPI_S);
-    int* mtab = sMtab + wave * 32;
-    float yv[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int prow = lh * 16 + q;               // patch row = tl * 4 + a * 2 + bb
-        const int tl = prow >> 2, a = (prow >> 1) & 1, bb = prow & 1;
-        const int t = wi * 8 + tl;
-        const float* Xh = X + wh * (4 * 2 * 32 * 32);
-        const float x0 = Xh[((0 * 2 + bb) * 32 + t) * 32 + lr], x1 = Xh[((1 * 2 + bb) * 32 + t) * 32 + lr];
-        const float x2 = Xh[((2 * 2 + bb) * 32 + t) * 32 + lr], x3 = Xh[((3 * 2 + bb) * 32 + t) * 32 + lr];
-        yv[q] = a == 0 ? (x0 + x1) + x2 : (x1 - x2) - x3;
-    }
-    __syncthreads();                                // everybody has read X: the patches go on top of it
-#pragma unroll
-    for (int q = 0; q < 16; ++q) sW[(lh * 16 + q) * EPI_S + lr] = yv[q];
-    if (lane < 32) {
-        const int tl = lane >> 2, a = (lane >> 1) & 1, bb = lane & 1;
-        const int t = wi * 8 + tl, ty = t / TWr, tx = t - ty * TWr;
-        const int oy = oy0 + 2 * ty + a, ox = ox0 + 2 * tx + bb;
-        mtab[lane] = (oy < Ho && ox < Wo) ? oy * Wo + ox : -1;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    patch_tail(p, sW, b, 0, n0, lane, Ho * Wo, 0, 4, 1, 0, mtab);
-    if (p.st_partial) patch_stats(p, sW, b, 0, n0, lane, Ho * Wo, mtab, reg * 4 + wi, nreg * 4);
-}
-
 // U = G g G^T of a packed direct matrix w [rows][tap][cin_pad] (BatchNorm folds, stacking, interleaving already applied),
 // stored [n-block][chunk][pos = i*4+j][32 n][8 k] with the 16-byte k quads of a row swapped for rows 8..15 and 24..31
 // (the swizzle conv_wino_kernel reads with); rows past `rows` are zero
@@ -1432,10 +1225,9 @@ static int wino_regions(int Ho, int Wo) {
 
 // statistics partials a convolution with st_partial writes per image: one per 32-pixel patch, or per Winograd tile row
 int conv_stats_chunks(const ConvParams& p, int tile) {
-    if (tile == 40 || tile == 41 || tile == 44 || tile == 45 || tile == 48) return wino_regions(p.Ho, p.Wo) * 4;
+    if (tile == 40 || tile == 44 || tile == 45 || tile == 48 || tile == 49) return wino_regions(p.Ho, p.Wo) * 4;
     if (tile == 42) return wino4_regions(p.Ho, p.Wo) * 16;
     if (tile == 47) return wino16_regions(p.Ho, p.Wo) * 2;
-    if (tile == 43) return patch_tiles(p.Ho, p.Wo) * 4;
     return (p.Ho * p.Wo + 31) / 32;
 }
 
@@ -1458,22 +1250,6 @@ static hipError_t launch_wino(const ConvParams& p, int batch, hipStream_t s) {
     if (wgs <= 0 || wgs >= 0x7FFFFFFFL) return hipErrorInvalidValue;
     g_last_launch.threads = wgs * 256;
     hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)wgs), dim3(256), 0, s, p);
-    return hipGetLastError();
-}
-
-static bool wino8_ok(const ConvParams& p) {
-    if (!wino_ok(p) || p.cout % 64 || p.cin_pad % W8_KC) return false;
-    for (int i = 0; i < p.nseg; ++i)
-        if (p.seg_c[i] % W8_KC) return false;
-    return true;
-}
-
-static hipError_t launch_wino8(const ConvParams& p, int batch, hipStream_t s) {
-    if (!wino8_ok(p)) return hipErrorInvalidValue;
-    const long wgs = (long)wino_regions(p.Ho, p.Wo) * (p.cout / 64) * batch;
-    if (wgs <= 0 || wgs >= 0x7FFFFFFFL) return hipErrorInvalidValue;
-    g_last_launch.threads = wgs * 512;
-    hipLaunchKernelGGL(conv_wino8_kernel, dim3((unsigned)wgs), dim3(512), 0, s, p);
     return hipGetLastError();
 }
 
@@ -1720,12 +1496,11 @@ const char* conv_tile_name(int tile) {
         case 33: return "conv_dma_kernel<128,64,2,2,1,16,nbuf4>";
         case 34: return "conv_dma_kernel<32,96,1,1,4,8>";
         case 40: return "conv_wino_kernel";
-        case 41: return "conv_wino8_kernel";
         case 42: return "conv_wino4_kernel";
         case 46: return "conv_wino1d_kernel";
         case 47: return "conv_wino16_kernel";
-        case 48: return "conv_wino_p_kernel";
-        case 43: return "conv_patch_kernel";
+        case 48: return "conv_wino_p_kernel<0>";
+        case 49: return "conv_wino_p_kernel<1>";
         case 44: return "conv_wino_sk_kernel<2>";
         case 45: return "conv_wino_sk_kernel<4>";
         default: return "?";
@@ -1737,7 +1512,7 @@ const char* conv_tile_name(int tile) {
 // direct kernels.  bench.py prices the executed-MFMA roofline fraction with it (per launch-site row, not by kernel-name prefix).
 double conv_tile_mfma_ratio(int tile) {
     switch (tile) {
-        case 40: case 41: case 44: case 45: case 47: case 48: return 4.0 / 9.0;
+        case 40: case 44: case 45: case 47: case 48: case 49: return 4.0 / 9.0;
         case 46: return 0.6;
         case 42: return 0.25;
         default: return 1.0;
@@ -1822,14 +1597,6 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
     }
     const bool auto_tile = tile == 0;
     if (tile == 0 && smalln_ok(p)) tile = 7;
-    // planar small-Cin inputs (encoder stems, We / Wi, the flow branch's 7x7): CF_PATCH=1 takes the LDS-resident patch kernel
-    // (conv_patch.hip) instead of the per-element gather of conv_igemm_kernel.  Off by default: measured equal on the 7x7 stems
-    // (66-68 us for the 5-channel one on BOTH kernels: 24 us of it is the fp32 MFMA floor of K = 245, the rest prologue, epilogue and
-    // exposed latency of a single under-filled round) and slower on We / Wi (31 vs 22 us)
-    if (tile == 0 && p.a_mode == A_GATHER && patch_ok(p)) {
-        static const int use_patch = getenv("CF_PATCH") ? atoi(getenv("CF_PATCH")) : 0;
-        if (use_patch) tile = 43;
-    }
     if (tile == 7 || tile == 15) {
         if (!smalln_ok(p)) return hipErrorInvalidValue;
         if (tile_used) *tile_used = 7;
@@ -1844,7 +1611,7 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
         const long tb = p.tile_batch > 0 ? p.tile_batch : batch;
         const long wg = (long)wino_regions(p.Ho, p.Wo) * ((p.cout + 31) / 32) * tb;
         static const long wmin = getenv("CF_WINO_MIN") ? atol(getenv("CF_WINO_MIN")) : 128;
-        if (wg >= wmin) tile = 40;      // (the eight-wave tile 41 measured -3..+6 % per layer, -1.4 % on the whole step: explicit only)
+        if (wg >= wmin) tile = 40;
         // Launches of at most CF_WINO_SK2_MAX workgroups (every CU gets ONE or none) split the chunks over 2 wave groups per workgroup
         // (conv_wino_sk.hip): +0.4 % on the step in three alternating A/B pairs on one box (1564 -> 1570 frames/s; menc.conv, encoder
         // stage 3).  CF_WINO_SK=0 turns it off.
@@ -1893,7 +1660,7 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
     // beside the other three's MFMAs, which is all the walk buys.  CF_WINOP=1 turns it on.
     if (auto_tile && tile == 40 && wino_p_ok(p)) {
         static const int winop = getenv("CF_WINOP") ? atoi(getenv("CF_WINOP")) : 0;
-        if (winop) tile = 48;
+        if (winop) tile = winop == 2 ? 49 : 48;
     }
     if (tile == 0) {
         // Pick the largest tile that still yields >= ~2 workgroups per CU (measured with tools/conv_bench.py on
@@ -1946,8 +1713,7 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
                 tile = wgs128x128 >= 2304 ? 25 : ((p.cout >= 256 && p.cout % 128 == 0) ? 28 : 23);
         }
     }
-    if (((tile >= 20 && tile <= 42) || tile == 44 || tile == 45 || tile == 47 || tile == 48) && !(p.a_mode == A_NHWC && dma_range_ok(p))) return hipErrorInvalidValue;
-    if (tile == 43 && !patch_ok(p)) return hipErrorInvalidValue;   // explicit DMA tile, image too large
+    if (((tile >= 20 && tile <= 40) || tile == 42 || tile == 44 || tile == 45 || tile == 47 || tile == 48 || tile == 49) && !(p.a_mode == A_NHWC && dma_range_ok(p))) return hipErrorInvalidValue;
     if (tile_used) *tile_used = tile;
     g_last_launch.kernel = conv_tile_name(tile);
     if (p.prec != 0 && p.prec != 1 && p.prec != 3) return hipErrorInvalidValue;
@@ -1990,12 +1756,11 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
         case 33: return launch_dma<128, 64, 2, 2, 1, 16, 4>(p, batch, s);
         case 34: return launch_dma<32, 96, 1, 1, 4, 8>(p, batch, s);
         case 40: return launch_wino(p, batch, s);
-        case 41: return launch_wino8(p, batch, s);
         case 42: return launch_wino4(p, batch, s);
-        case 43: return launch_patch(p, batch, s);
         case 46: return launch_wino1d(p, batch, s);
         case 47: return launch_wino16(p, batch, s);
-        case 48: return launch_wino_p(p, batch, s);
+        case 48: return launch_wino_p(p, batch, s, 0);
+        case 49: return launch_wino_p(p, batch, s, 1);
         case 44: return wino_ok(p) ? launch_wino_sk(p, batch, s, 2) : hipErrorInvalidValue;
         case 45: return wino_ok(p) ? launch_wino_sk(p, batch, s, 4) : hipErrorInvalidValue;
         default: return hipErrorInvalidValue;

@@ -23,13 +23,22 @@
 
 namespace cf {
 
-static constexpr int WP_X0 = WG_RAW;                        // floats: the exchange buffer begins behind raw buffer 0
 static constexpr int WP_A = 4 * 2 * 32 * 32;                // floats of the exchange buffer X[4][2][32][32]
-static constexpr int WP_SMEM = WP_X0 + WP_A;                // 10,240 floats = 40,960 bytes
-static_assert(2 * WG_RAW <= WP_SMEM, "raw buffer 1 lies inside the exchange buffer");
 static_assert(4 * 32 * EPI_S + 4 * 32 <= WP_A, "epilogue patches + row -> pixel tables fit the dead exchange buffer");
 
-__global__ __launch_bounds__(256, 4) void conv_wino_p_kernel(const ConvParams p, const int NR, const int R) {
+// PIPE = 1 (tile 49): the chunk loop is SOFTWARE-PIPELINED -- the A operands of chunk k + 1 are read from LDS and transformed in the
+// issue slots BETWEEN the sixteen MFMAs of chunk k (af_cur / af_nxt), the raw patch is requested two chunks ahead, and nothing but the
+// hand-off barrier stands between one chunk's MFMAs and the next one's.  Why: PMC + stamps of the gate convolution (r04) put the matrix
+// pipe at 82 % busy over the waves' lifetime although four waves share each SIMD -- per chunk a wave spends ~1.6 k cycles (barrier, DMA
+// issue, eight LDS reads, 48 VALU) in which it cannot feed the pipe, and during a workgroup's tail only three waves are left to cover
+// for one another.  The pipelined loop needs 16 more registers (af_nxt) and keeps both raw buffers live across the tail (the next item's
+// chunk 1 is landing): 48 KB of LDS and <= 168 VGPRs, i.e. THREE workgroups per CU -- which is enough once a wave's off-pipe time per
+// chunk is a few hundred cycles.  Same arithmetic, bit for bit.
+template <int PIPE>
+__global__ __launch_bounds__(256, PIPE ? 3 : 4) void conv_wino_p_kernel(const ConvParams p, const int NR, const int R) {
+    constexpr int WP_X0 = PIPE ? 2 * WG_RAW : WG_RAW;       // floats: the exchange buffer begins behind raw buffer 0 (PIPE: behind both)
+    constexpr int WP_SMEM = WP_X0 + WP_A;                   // 40,960 bytes (PIPE: 49,152)
+    static_assert(2 * WG_RAW <= WP_SMEM, "raw buffer 1 lies inside the exchange buffer");
 #ifdef CF_STAMP
     const long long t_begin = __builtin_readcyclecounter();
     const long long r_begin = (long long)__builtin_amdgcn_s_memrealtime();
@@ -201,15 +210,114 @@ __global__ __launch_bounds__(256, 4) void conv_wino_p_kernel(const ConvParams p,
         }
     };
 
+    // ---- PIPE: one chunk step = sixteen slots of {one MFMA of chunk k; a slice of the work for chunk k + 1 / k + 2}, pinned in this order ----
+    f32x4 af_cur[4], af_nxt[4];
+    auto transform_now = [&](int buf, f32x4 (&af)[4]) __attribute__((always_inline)) {      // prologue only: raw(0) -> operands of chunk 0
+        const float* r = sRaw + buf * WG_RAW;
+        f32x4 t[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int col = ((c >> 1) + (c & 1) * PCh) * 4;
+            const f32x4 da = *reinterpret_cast<const f32x4*>(r + rd_a + col), db = *reinterpret_cast<const f32x4*>(r + rd_b + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[c][e] = __builtin_fmaf(sgn, db[e], da[e]);
+        }
+        af[0] = t[0] - t[2];
+        af[1] = t[1] + t[2];
+        af[2] = t[2] - t[1];
+        af[3] = t[1] - t[3];
+    };
+    // k: chunk whose MFMAs run; live: the chunk two steps ahead exists (in this item or the next); u_next: byte offset of the U block one step ahead
+    auto pchunk_step = [&](int k, bool live, unsigned u_next) __attribute__((always_inline)) {
+        const float* r = sRaw + ((k + 1) & 1) * WG_RAW;
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(seg_base);
+        const unsigned ld4 = (unsigned)seg_ld * 4u, so = (unsigned)it_cs * 4u;
+        float* rbase = sRaw + (k & 1) * WG_RAW;        // raw(k + 2) goes where raw(k) was
+        f32x4 da, db, t[4];
+#define WP_SLOT(j, s2, ...)                                                                                   \
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af_cur[j][s2], bu[j][s2], acc[j], 0, 0, 0);             \
+        __VA_ARGS__;                                                                                          \
+        __builtin_amdgcn_sched_barrier(0)
+#define WP_DMA(jj)                                                                                            \
+        dma16_to_lds(rs, rbase + (256 * jj + 64 * wave) * 4,                                                  \
+                     (a_pix[jj] < 0 || !live) ? BUF_OOB : __umul24((unsigned)a_pix[jj], ld4) + a_q[jj], so)
+#define WP_RD(c)                                                                                              \
+        da = *reinterpret_cast<const f32x4*>(r + rd_a + ((c >> 1) + (c & 1) * PCh) * 4);                     \
+        db = *reinterpret_cast<const f32x4*>(r + rd_b + ((c >> 1) + (c & 1) * PCh) * 4)
+        // (pure arithmetic carries no ordering: without the empty asm the compiler sinks the whole transform behind the last MFMA)
+#define WP_PIN(x) asm volatile("" : "+v"(x))
+#define WP_T(c)                                                                                               \
+        t[c][0] = __builtin_fmaf(sgn, db[0], da[0]); t[c][1] = __builtin_fmaf(sgn, db[1], da[1]);            \
+        t[c][2] = __builtin_fmaf(sgn, db[2], da[2]); t[c][3] = __builtin_fmaf(sgn, db[3], da[3]); WP_PIN(t[c])
+        // The MFMAs only need registers (af_cur, bu), so position 0's four run BEFORE the hand-off barrier: 256 cycles of matrix-pipe work
+        // during which the workgroup's other waves arrive (a wave that waits at the barrier while its SIMD's pipe has a free slot is the
+        // bubble this removes); everything that touches the raw buffers comes behind the barrier.
+        WP_SLOT(0, 0, (void)0);
+        WP_SLOT(0, 1, (void)0);
+        WP_SLOT(0, 2, (void)0);
+        WP_SLOT(0, 3, (void)0);
+#ifdef CF_STAMP
+        const long long t0 = __builtin_readcyclecounter();
+#endif
+        // in flight, oldest first: the two pieces of raw(k + 1) (issued one step earlier), then the four U(k) loads
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        raw_barrier();                              // raw(k + 1) has landed for everybody; everybody has read raw(k) (one step earlier) / finished its tail
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef CF_STAMP
+        const long long t1 = __builtin_readcyclecounter();
+        st_wait += t1 - t0;
+#endif
+        WP_SLOT(1, 0, WP_DMA(0));
+        WP_SLOT(1, 1, WP_DMA(1); bu[0] = buf_load4(u_rsrc, uoff, u_next));
+        WP_SLOT(1, 2, WP_RD(0));
+        WP_SLOT(1, 3, bu[1] = buf_load4(u_rsrc, uoff + 1024u, u_next));
+        WP_SLOT(2, 0, WP_T(0); WP_RD(1));
+        WP_SLOT(2, 1, WP_T(1); WP_RD(2));
+        WP_SLOT(2, 2, WP_T(2); WP_RD(3));
+        WP_SLOT(2, 3, WP_T(3); bu[2] = buf_load4(u_rsrc, uoff + 2048u, u_next));
+        WP_SLOT(3, 0, af_nxt[0] = t[0] - t[2]; WP_PIN(af_nxt[0]));
+        WP_SLOT(3, 1, af_nxt[1] = t[1] + t[2]; WP_PIN(af_nxt[1]));
+        WP_SLOT(3, 2, af_nxt[2] = t[2] - t[1]; WP_PIN(af_nxt[2]));
+        WP_SLOT(3, 3, af_nxt[3] = t[1] - t[3]; WP_PIN(af_nxt[3]); bu[3] = buf_load4(u_rsrc, uoff + 3072u, u_next));
+#undef WP_SLOT
+#undef WP_DMA
+#undef WP_RD
+#undef WP_T
+#undef WP_PIN
+#pragma unroll
+        for (int j = 0; j < 4; ++j) af_cur[j] = af_nxt[j];
+        // advance the raw-patch iterator (it names chunk k + 3 now)
+        it_cs += WG_KC;
+        if (it_cs >= seg_cn) {
+            it_cs = 0;
+            ++it_seg;
+            if (it_seg < p.nseg) {
+                seg_base = sel3(p.in, it_seg) + (long)it_b * (it_seg == 1 ? p.seg_bs[1] : p.seg_bs[2]);
+                seg_ld = it_seg == 1 ? p.seg_ld[1] : p.seg_ld[2];
+                seg_cn = it_seg == 1 ? p.seg_c[1] : p.seg_c[2];
+            }
+        }
+#ifdef CF_STAMP
+        st_issue += __builtin_readcyclecounter() - t1;
+#endif
+    };
+
     int item = walker;
     int c_b, c_reg, c_oy0, c_ox0;
     unsigned u_base;
     setup(item, c_b, c_reg, c_oy0, c_ox0, u_base);
     issue_raw(0, true);
+    if constexpr (PIPE) issue_raw(1, true);             // (nchunk >= 2: wino_p_ok)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) bu[j] = buf_load4(u_rsrc, uoff + 1024u * j, u_base);
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PIPE) {
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // raw(0) has landed (raw(1) and U(0) may still be on their way)
+        raw_barrier();
+        transform_now(0, af_cur);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 #ifdef CF_STAMP
     st_first = __builtin_readcyclecounter() - t_begin;
 #endif
@@ -226,10 +334,19 @@ __global__ __launch_bounds__(256, 4) void conv_wino_p_kernel(const ConvParams p,
         const bool has_next = nxt < cnt_x;
         int n_b = c_b, n_reg = c_reg, n_oy0 = c_oy0, n_ox0 = c_ox0;
         unsigned n_ubase = u_base;
+        if constexpr (PIPE) {
+            // steps 0 .. nchunk - 3 request raw patches of THIS item (two ahead); the last two request the next item's chunks 0 and 1, and
+            // the very last one transforms the next item's chunk 0 and loads its U(0): the chunk loop runs on across the tail
+            for (int k = 0; k < nchunk - 2; ++k) pchunk_step(k, true, u_base + (unsigned)(k + 1) * (WG_UV * 4u));
+            if (has_next) setup(nxt, n_b, n_reg, n_oy0, n_ox0, n_ubase);
+            pchunk_step(nchunk - 2, has_next, u_base + (unsigned)(nchunk - 1) * (WG_UV * 4u));
+            pchunk_step(nchunk - 1, has_next, has_next ? n_ubase : u_base + (unsigned)(nchunk - 1) * (WG_UV * 4u));
+        } else {
         for (int k = 0; k < nchunk - 1; ++k) chunk_step(k, true, u_base + (unsigned)(k + 1) * (WG_UV * 4u));
         // the last chunk step of the item requests the NEXT item's first raw patch and U block (none left: dead requests, as in conv_wino_kernel)
         if (has_next) setup(nxt, n_b, n_reg, n_oy0, n_ox0, n_ubase);
         chunk_step(nchunk - 1, has_next, has_next ? n_ubase : u_base + (unsigned)(nchunk - 1) * (WG_UV * 4u));
+        }
 #ifdef CF_STAMP
         const long long tl1 = __builtin_readcyclecounter();
         st_loop += tl1 - tl0;
@@ -324,9 +441,9 @@ bool wino_p_ok(const ConvParams& p) {
 }
 
 // walkers per (XCD, n-block): as many as fit 4 workgroups per CU (CF_WINOP_SLOTS workgroups in all), no more than an XCD has items
-int wino_p_walkers(const ConvParams& p, long NR) {
+int wino_p_walkers(const ConvParams& p, long NR, int pipe) {
     const char* es = getenv("CF_WINOP_SLOTS");              // read per launch: the tests shrink it to make every walker carry several items
-    const long slots = es ? atol(es) : 1024;
+    const long slots = es ? atol(es) : (pipe ? 768 : 1024);     // workgroups the chip holds at once (3 / 4 per CU)
     const long nt = (p.cout + 31) / 32;
     long R = slots / (8 * nt);
     if (R < 1) R = 1;
@@ -341,7 +458,7 @@ int wino_p_walkers(const ConvParams& p, long NR) {
     return (int)R;
 }
 
-hipError_t launch_wino_p(const ConvParams& p, int batch, hipStream_t s) {
+hipError_t launch_wino_p(const ConvParams& p, int batch, hipStream_t s, int pipe) {
     if (!wino_p_ok(p)) return hipErrorInvalidValue;
     const long nreg = wino_tall(p.Ho, p.Wo) ? (long)((p.Ho + 15) / 16) * ((p.Wo + 7) / 8) : (long)((p.Ho + 7) / 8) * ((p.Wo + 15) / 16);
     const long NR = nreg * batch;
@@ -352,11 +469,12 @@ hipError_t launch_wino_p(const ConvParams& p, int batch, hipStream_t s) {
     if (p.wino_gs < 0) return hipErrorInvalidValue;
     const long ubytes = (last_group * p.wino_gs + nt * (p.cin_pad / WG_KC) * WG_UV) * 4L;
     if (ubytes >= 0x7FFFFF00L) return hipErrorInvalidValue;
-    const int R = wino_p_walkers(p, NR);
+    const int R = wino_p_walkers(p, NR, pipe);
     const long wgs = 8 * nt * R;
     if (wgs >= 0x7FFFFFFFL) return hipErrorInvalidValue;
     g_last_launch.threads = wgs * 256;
-    hipLaunchKernelGGL(conv_wino_p_kernel, dim3((unsigned)wgs), dim3(256), 0, s, p, (int)NR, R);
+    if (pipe) hipLaunchKernelGGL(conv_wino_p_kernel<1>, dim3((unsigned)wgs), dim3(256), 0, s, p, (int)NR, R);
+    else hipLaunchKernelGGL(conv_wino_p_kernel<0>, dim3((unsigned)wgs), dim3(256), 0, s, p, (int)NR, R);
     return hipGetLastError();
 }
 

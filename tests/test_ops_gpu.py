@@ -140,9 +140,6 @@ STATS_CASES = [
     (64, 96, 3, 3, 2, 1, 0, 0, 96, 128),     # ... as the launcher picks it for the 96-channel stage
     (64, 64, 3, 3, 1, 1, 0, 40, 48, 64),     # Winograd tile: one partial per tile row of an 8 x 16 region
     (96, 96, 3, 3, 1, 1, 0, 40, 21, 37),     # ... ragged regions
-    (64, 128, 3, 3, 1, 1, 0, 41, 21, 37),    # eight-wave Winograd tile
-    (1, 64, 7, 7, 2, 3, 2, 43, 37, 53),      # patch kernel (planar small-Cin input), ragged tiles
-    (5, 64, 7, 7, 2, 3, 2, 43, 64, 80),
     (96, 96, 3, 3, 1, 1, 0, 44, 21, 37),     # split-K Winograd (2 / 4 wave groups)
     (128, 128, 3, 3, 1, 1, 0, 45, 24, 32),
     (64, 64, 3, 3, 1, 1, 0, 42, 48, 64),     # F(4x4,3x3): sixteen partials per 32-tile region
@@ -151,6 +148,8 @@ STATS_CASES = [
     (64, 160, 3, 3, 1, 1, 0, 40, 17, 17),
     (64, 64, 3, 3, 1, 1, 0, 48, 48, 64),     # persistent Winograd workgroups: the partials of every item a walker carries
     (96, 96, 3, 3, 1, 1, 0, 48, 21, 37),
+    (64, 64, 3, 3, 1, 1, 0, 49, 48, 64),     # ... software-pipelined variant
+    (96, 96, 3, 3, 1, 1, 0, 49, 21, 37),
     (96, 128, 3, 3, 1, 1, 0, 47, 13, 19),    # conv_wino16_kernel: two statistics patches per 8 x 8 region, ragged
     (64, 64, 3, 3, 1, 1, 0, 47, 24, 32),
 ]
@@ -228,15 +227,17 @@ def test_conv_winograd(gpu, case):
     assert (got - direct).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
     # persistent workgroups (tile 48, conv_wino_p_kernel): the same arithmetic, bit for bit -- with the default grid (one item per
     # walker at these sizes) and with the grid shrunk to one walker per (XCD, n-block), which then walks its XCD's whole run of regions
+    # ... and the same with the software-pipelined chunk loop (tile 49: operands of chunk k + 1 built between the MFMAs of chunk k)
     import os
-    gp = run_conv(gpu, x, w, b, 1, 1, 1, pad_mode, 0, epi, 48, H, W)
-    assert torch.equal(gp, got)
-    os.environ["CF_WINOP_SLOTS"] = "8"
-    try:
-        gp1 = run_conv(gpu, x, w, b, 1, 1, 1, pad_mode, 0, epi, 48, H, W)
-    finally:
-        del os.environ["CF_WINOP_SLOTS"]
-    assert torch.equal(gp1, got)
+    for ptile in (48, 49):
+        gp = run_conv(gpu, x, w, b, 1, 1, 1, pad_mode, 0, epi, ptile, H, W)
+        assert torch.equal(gp, got), ptile
+        os.environ["CF_WINOP_SLOTS"] = "8"
+        try:
+            gp1 = run_conv(gpu, x, w, b, 1, 1, 1, pad_mode, 0, epi, ptile, H, W)
+        finally:
+            del os.environ["CF_WINOP_SLOTS"]
+        assert torch.equal(gp1, got), ptile
     for sk_tile in (44, 45):                   # chunks split over 2 / 4 wave groups of a workgroup (odd chunk counts: dead steps)
         gsk = run_conv(gpu, x, w, b, 1, 1, 1, pad_mode, 0, epi, sk_tile, H, W)
         assert (gsk - ref).abs().max().item() < 1e-4, sk_tile
@@ -246,10 +247,6 @@ def test_conv_winograd(gpu, case):
     assert (g16 - ref).abs().max().item() < 1e-4
     assert (g16 - got).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
     assert torch.equal(g16, run_conv(gpu, x, w, b, 1, 1, 1, pad_mode, 0, epi, 47, H, W))
-    if Cout % 64 == 0 and Cin % 16 == 0:       # the eight-wave kernel (tile 41): 64 output channels x 16-channel chunks
-        got8 = run_conv(gpu, x, w, b, 1, 1, 1, pad_mode, 0, epi, 41, H, W)
-        assert (got8 - ref).abs().max().item() < 1e-4
-        assert (got8 - direct).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
 WINO4_CASES = WINO_CASES + [(64, 64, 1, 96, 128, 1), (128, 64, 1, 37, 50, 0), (16, 40, 0, 12, 12, 0), (80, 32, 1, 16, 32, 0),
@@ -328,7 +325,7 @@ def test_conv_epilogue_activation(gpu, epi):
                                   (2, 128, 7, 1, 3, 0)])
 def test_conv_gather_small_cin(gpu, case):
     """Planar small-Cin inputs (encoder stems, We / Wi, convf1): the per-element gather of conv_igemm_kernel (what the launcher
-    picks, and explicit tile 2) and the opt-in LDS-resident patch kernel (tile 43) against F.conv2d -- ragged sizes, one tile and
+    picks, and explicit tile 2) against F.conv2d -- ragged sizes, one tile and
     many, fused ReLU."""
     Cin, Cout, K, stride, pad, pad_mode = case
     g = torch.Generator().manual_seed(11 + Cin + K)
@@ -341,7 +338,7 @@ def test_conv_gather_small_cin(gpu, case):
         ref = ref_conv(x, w, b, stride, pad, pad, pad_mode)
         if epi == 1:
             ref = torch.relu(ref)
-        for tile in (0, 43, 2):
+        for tile in (0, 2):
             got = run_conv(gpu, x, w, b, stride, pad, pad, pad_mode, 2, epi, tile, ref.shape[2], ref.shape[3])
             assert got.shape == ref.shape and (got - ref).abs().max().item() < 1e-4, (B, H, W, tile)
 

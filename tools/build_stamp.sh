@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/.."
 python -c "import __graft_entry__ as g; g.compile_objects()" >/dev/null
 objs=""
-for f in conv_igemm conv_wino4 conv_wino_sk conv_wino1d conv_wino16 conv_wino_p conv_patch pointwise metrics cf_api; do
+for f in conv_igemm conv_wino4 conv_wino_sk conv_wino1d conv_wino16 conv_wino_p pointwise metrics cf_api; do
   case $f in
     conv_igemm|conv_wino_p|conv_wino16|conv_wino1d)
       hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter -DCF_STAMP -c cista_flow_amd/csrc/$f.hip -o build_var/stamp.$f.o &

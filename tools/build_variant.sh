@@ -9,7 +9,7 @@ mkdir -p build_var/obj
 python -c "import __graft_entry__ as g; g.compile_objects()" >/dev/null
 hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter "$@" -c cista_flow_amd/csrc/$src -o build_var/$name.${src%.hip}.o
 objs=""
-for f in conv_igemm conv_wino4 conv_wino_sk conv_wino1d conv_wino16 conv_wino_p conv_patch pointwise metrics cf_api; do
+for f in conv_igemm conv_wino4 conv_wino_sk conv_wino1d conv_wino16 conv_wino_p pointwise metrics cf_api; do
   if [ "$f.hip" == "$src" ]; then objs="$objs build_var/$name.$f.o"; else objs="$objs build_var/obj/$f.o"; fi
 done
 hipcc --offload-arch=gfx950 -shared -fPIC -o build_var/$name.so $objs

@@ -49,9 +49,9 @@ for case in CASES.split(","):
               " | prologue %6.0f  loop %7.0f  tail %6.0f cycles | shader clock %4.0f MHz" % (
                   shape[0], r[0], r[1], n, m[0] / n, (m[5] - m[0]) / n, m[3], m[5], m[6], m[7]), flush=True)
         continue
-    if int(tile) == 48:     # conv_wino_p_kernel: [DMA wait + barrier, items, issue + transform, begin -> first chunk step, chunks (all items), loops, tails, MHz]
+    if int(tile) in (48, 49):     # conv_wino_p_kernel<0 | 1>: [DMA wait + barrier, items, issue + transform, begin -> first chunk step, chunks (all items), loops, tails, MHz]
         items = d[:, 1].mean().item()
-        print("%-34s tile 48  %7.1f us %5.1f TF | items per workgroup %4.2f (max %d) | per chunk: dma-wait+barrier %4.0f  issue+transform %4.0f  frag reads + 16 mfma %4.0f"
+        print("%-34s tile 4x  %7.1f us %5.1f TF | items per workgroup %4.2f (max %d) | per chunk: dma-wait+barrier %4.0f  issue+transform %4.0f  frag reads + 16 mfma %4.0f"
               " | begin -> first chunk step %6.0f (once per workgroup)  per item: loop %7.0f  tail + hand-over %6.0f cycles | shader clock %4.0f MHz" % (
                   shape[0], r[0], r[1], items, int(d[:, 1].max().item()), m[0] / n, m[2] / n, (m[5] - m[0] - m[2]) / n, m[3], m[5] / items, m[6] / items, m[7]), flush=True)
         continue
