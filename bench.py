@@ -235,13 +235,15 @@ def roofline_pass(model, step, B, dev, nprof):
         b_ms = sum(r["ms"] for r in rows if sel(r) and r["class"] == "hbm")
         b_w = sum(r["work"] for r in rows if sel(r) and r["class"] == "hbm")
         tot = m_ms + b_ms
-        mfr = (m_w / (m_ms * 1e-3) / 1e12 / mfma_peak()) if m_ms else None
+        mfr = (m_w / (m_ms * 1e-3) / 1e12 / mfma_peak()) if m_ms else None          # algorithmic flops (may pass 1: Winograd)
+        mxr = (m_x / (m_ms * 1e-3) / 1e12 / mfma_peak()) if m_ms else None          # executed on the matrix cores (<= 1)
         hfr = (b_w / (b_ms * 1e-3) / 1e12 / PEAK_HBM_TBS) if b_ms else None
-        comb = ((m_ms * (mfr or 0) + b_ms * (hfr or 0)) / tot) if tot else None
+        comb = ((m_ms * (mxr or 0) + b_ms * (hfr or 0)) / tot) if tot else None
         return {"ms_per_step": round(tot / nprof, 3), "mfma_ms_per_step": round(m_ms / nprof, 3), "hbm_ms_per_step": round(b_ms / nprof, 3),
-                # mfma_frac prices ALGORITHMIC flops (can pass 1 where Winograd launches dominate); mfma_executed_frac the executed ones
-                "mfma_frac": None if mfr is None else round(mfr, 4),
-                "mfma_executed_frac": round(m_x / (m_ms * 1e-3) / 1e12 / mfma_peak(), 4) if m_ms else None,
+                # roofline fractions (<= 1): executed matrix-core flops against the fp32 MFMA peak, algorithmic bytes against the HBM peak,
+                # and their time-weighted combination; the algorithmic-flop figure stands beside them
+                "mfma_executed_frac": None if mxr is None else round(mxr, 4),
+                "mfma_algorithmic_frac": None if mfr is None else round(mfr, 4),
                 "hbm_frac": None if hfr is None else round(hfr, 4),
                 "time_weighted_frac": None if comb is None else round(comb, 4)}
 

@@ -1399,25 +1399,16 @@ static int encoder_forward(cf_handle* h, const std::string& pre, bool bn, const 
                 c1.st_partial = sc.partial;
                 CF_HIP(h, run_conv(h, c1, BB, st));
                 nch = conv_stats_chunks(c1, h->last_tile);
-                // CF_INORM_FUSED=1 (opt-in): on the small maps (stages 2, 3) the fold of the partials and the normalisation are ONE launch,
-                // bit-identical -- and measured 0.6 % SLOWER on the step (four alternating A/B pairs): every workgroup then waits for its
-                // own fold (a fabric round trip + a 64-term fp64 chain) before it streams, which costs more than the launch it saves
-                const int fuse_env = getenv("CF_INORM_FUSED") ? atoi(getenv("CF_INORM_FUSED")) : 0;      // read per call: tests flip it
-                if (fuse_env && inorm_fapply_ok(nch, Ho * Wo, Cd)) {
-                    PROF(h, st, "enc.inorm_fapply", 8.0 * BB * Ho * Wo * Cd + 16.0 * BB * nch * Cd);
-                    CF_HIP(h, launch_inorm_fapply(Bf, Cd, obs, sc.partial, nch, eps, nullptr, 0, 0, nullptr, Cf, Cd, obs, BB, Ho * Wo, Cd, st));
-                } else {
-                    { PROF(h, st, "enc.inorm_final", 16.0 * BB * nch * Cd); CF_HIP(h, launch_inorm_final(sc.partial, nch, BB, Ho * Wo, Cd, eps, sc.stats, st)); }
-                    { PROF(h, st, "enc.inorm_apply", 8.0 * BB * Ho * Wo * Cd); CF_HIP(h, launch_inorm_apply(Bf, Cd, obs, sc.stats, nullptr, 0, 0, nullptr, Cf, Cd, obs, BB, Ho * Wo, Cd, st)); }
-                }
+                // (fold of the partials + normalisation as ONE launch -- inorm_fapply_kernel, r03 -- was bit-identical and measured 0.6 %
+                // slower on the step at B = 8 and neutral at B = 1 / 2 / 4 (r04): every workgroup then waits for its own fold before it
+                // streams, which costs more than the launch it saves; removed in r04)
+                { PROF(h, st, "enc.inorm_final", 16.0 * BB * nch * Cd); CF_HIP(h, launch_inorm_final(sc.partial, nch, BB, Ho * Wo, Cd, eps, sc.stats, st)); }
+                { PROF(h, st, "enc.inorm_apply", 8.0 * BB * Ho * Wo * Cd); CF_HIP(h, launch_inorm_apply(Bf, Cd, obs, sc.stats, nullptr, 0, 0, nullptr, Cf, Cd, obs, BB, Ho * Wo, Cd, st)); }
                 ConvParams c2 = nhwc_conv(K(b + ".conv2"), {{Cf, Cd, Cd, obs}}, Ho, Wo, Ho, Wo, 1, 1, 1, 0, Bf, Cd, obs, EPI_NONE);
                 c2.st_partial = sc.partial;
                 CF_HIP(h, run_conv(h, c2, BB, st));
                 nch = conv_stats_chunks(c2, h->last_tile);
-                // stride-1 blocks: nothing else needs the partial buffer before the residual step, so conv2's fold rides in that launch too
-                const bool fuse2 = fuse_env && stride == 1 && inorm_fapply_ok(nch, Ho * Wo, Cd);
-                if (!fuse2)
-                    { PROF(h, st, "enc.inorm_final", 16.0 * BB * nch * Cd); CF_HIP(h, launch_inorm_final(sc.partial, nch, BB, Ho * Wo, Cd, eps, sc.stats, st)); }
+                { PROF(h, st, "enc.inorm_final", 16.0 * BB * nch * Cd); CF_HIP(h, launch_inorm_final(sc.partial, nch, BB, Ho * Wo, Cd, eps, sc.stats, st)); }
                 const float* res = A;
                 int res_ld = Cx;
                 long res_bs = ibs;
@@ -1430,10 +1421,7 @@ static int encoder_forward(cf_handle* h, const std::string& pre, bool bn, const 
                     { PROF(h, st, "enc.inorm_final", 16.0 * BB * nch * Cd); CF_HIP(h, launch_inorm_final(sc.partial, nch, BB, Ho * Wo, Cd, eps, sc.stats2, st)); }
                     res = Cf; res_ld = Cd; res_bs = obs; res_stats = sc.stats2;
                 }
-                if (fuse2) {
-                    PROF(h, st, "enc.inorm_fapply_res", 12.0 * BB * Ho * Wo * Cd + 16.0 * BB * nch * Cd);
-                    CF_HIP(h, launch_inorm_fapply(Bf, Cd, obs, sc.partial, nch, eps, res, res_ld, res_bs, res_stats, Df, Cd, obs, BB, Ho * Wo, Cd, st));
-                } else {
+                {
                     PROF(h, st, "enc.inorm_apply_res", 12.0 * BB * Ho * Wo * Cd);
                     CF_HIP(h, launch_inorm_apply(Bf, Cd, obs, sc.stats, res, res_ld, res_bs, res_stats, Df, Cd, obs, BB, Ho * Wo, Cd, st));
                 }

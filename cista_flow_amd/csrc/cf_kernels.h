@@ -203,11 +203,6 @@ hipError_t launch_inorm_stats(const float* x, int ld, long bs, int B, int HW, in
 hipError_t launch_inorm_apply(const float* x, int ld, long bs, const float* stats,
                               const float* res, int res_ld, long res_bs, const float* res_stats,
                               float* out, int out_ld, long out_bs, int B, int HW, int C, hipStream_t s);
-// launch_inorm_final + launch_inorm_apply in one launch where inorm_fapply_ok (<= 128 partials per image, C % 32 == 0): bit-identical
-bool inorm_fapply_ok(int nchunk, int HW, int C);
-hipError_t launch_inorm_fapply(const float* x, int ld, long bs, const double* partial, int nchunk, float eps, const float* res,
-                               int res_ld, long res_bs, const float* res_stats, float* out, int out_ld, long out_bs, int B, int HW,
-                               int C, hipStream_t s);
 
 // correlation pyramid: dst[b][i][y][x] = avg 2x2 of src
 hipError_t launch_corr_pool(const float* src, float* dst, long rows, int Hs, int Ws, hipStream_t s);

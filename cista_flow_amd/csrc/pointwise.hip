@@ -426,103 +426,6 @@ hipError_t launch_inorm_apply(const float* x, int ld, long bs, const float* stat
 }
 
 
-// inorm_final + inorm_apply in ONE launch for the small maps (encoder stages 2 and 3: <= 128 partials per image): a workgroup =
-// (image, 32 channels, slice of the pixels) first folds the partials of its 32 channels -- the very same order of additions as
-// inorm_final_kernel (thread row k takes chunks k, k + 64; one thread per channel then adds the 64 row sums in order), all loads in
-// flight at once -- and then normalises its slice with inorm_apply_kernel's expressions: bit-identical to the two launches, one ~6.5 us
-// launch fewer per normalisation on the encoders' dependent chains.  OPT-IN (CF_INORM_FUSED=1): measured 0.6 % slower on the step than
-// the two launches (the fold's latency is paid inside every workgroup before it can stream).  The fold is repeated by every pixel slice of a channel group
-// (48 KB of L2 hits each), which is why stage 1 (384 partials per image) keeps the separate fold.
-__global__ __launch_bounds__(256) void inorm_fapply_kernel(const float* __restrict__ x, int ld, long bs, const double* __restrict__ partial,
-                                                           int nchunk, float eps, const float* __restrict__ res, int res_ld, long res_bs,
-                                                           const float* __restrict__ res_stats, float* __restrict__ out, int out_ld,
-                                                           long out_bs, int HW, int C, int per) {
-    __shared__ double sh[8][64][4][2];
-    __shared__ float mr[32][2];
-    const int b = blockIdx.z, cg = blockIdx.y, t = threadIdx.x;
-    {
-        const int cl = t & 3, k = t >> 2;
-        double2 v0[8], v1[8];
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const double* src = partial + ((long)b * nchunk * C + cg * 32 + p * 4 + cl) * 2;
-            v0[p].x = 0.0; v0[p].y = 0.0; v1[p].x = 0.0; v1[p].y = 0.0;
-            if (k < nchunk) v0[p] = *reinterpret_cast<const double2*>(src + (long)k * C * 2);
-            if (k + 64 < nchunk) v1[p] = *reinterpret_cast<const double2*>(src + (long)(k + 64) * C * 2);
-        }
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            double s_ = 0.0, ss = 0.0;
-            s_ += v0[p].x; ss += v0[p].y;
-            s_ += v1[p].x; ss += v1[p].y;
-            sh[p][k][cl][0] = s_;
-            sh[p][k][cl][1] = ss;
-        }
-    }
-    __syncthreads();
-    if (t < 32) {
-        const int p = t >> 2, cl = t & 3;
-        double a = 0.0, aa = 0.0;
-#pragma unroll 8
-        for (int r = 0; r < 64; ++r) {
-            a += sh[p][r][cl][0];
-            aa += sh[p][r][cl][1];
-        }
-        const double mean = a / (double)HW;
-        double var = aa / (double)HW - mean * mean;
-        if (var < 0.0) var = 0.0;
-        mr[t][0] = (float)mean;
-        mr[t][1] = (float)(1.0 / sqrt(var + (double)eps));
-    }
-    __syncthreads();
-    const int q = t & 7, c0 = cg * 32 + q * 4;
-    const int p_end = min(HW, (int)(blockIdx.x + 1) * per);
-    float m4[4], r4[4], rm[4], rr[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        m4[e] = mr[q * 4 + e][0];
-        r4[e] = mr[q * 4 + e][1];
-        rm[e] = 0.f;
-        rr[e] = 1.f;
-    }
-    if (res && res_stats) {
-        const float* rs = res_stats + ((long)b * C + c0) * 2;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { rm[e] = rs[2 * e]; rr[e] = rs[2 * e + 1]; }
-    }
-    for (int p = (int)blockIdx.x * per + (t >> 3); p < p_end; p += 32) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(x + (long)b * bs + (long)p * ld + c0);
-        f32x4 r;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) r[e] = fmaxf((v[e] - m4[e]) * r4[e], 0.f);
-        if (res) {
-            f32x4 rv = *reinterpret_cast<const f32x4*>(res + (long)b * res_bs + (long)p * res_ld + c0);
-            if (res_stats) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) rv[e] = (rv[e] - rm[e]) * rr[e];
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] = fmaxf(rv[e] + r[e], 0.f);
-        }
-        *reinterpret_cast<f32x4*>(out + (long)b * out_bs + (long)p * out_ld + c0) = r;
-    }
-}
-
-bool inorm_fapply_ok(int nchunk, int HW, int C) { return nchunk > 0 && nchunk <= 128 && (C % 32) == 0 && HW > 0 && HW <= 16384; }
-
-hipError_t launch_inorm_fapply(const float* x, int ld, long bs, const double* partial, int nchunk, float eps, const float* res,
-                               int res_ld, long res_bs, const float* res_stats, float* out, int out_ld, long out_bs, int B, int HW,
-                               int C, hipStream_t s) {
-    if (!x || !partial || !out || !inorm_fapply_ok(nchunk, HW, C) || B <= 0 || B > 65535) return hipErrorInvalidValue;
-    if ((ld % 4) != 0 || (out_ld % 4) != 0 || (bs % 4) != 0 || (out_bs % 4) != 0) return hipErrorInvalidValue;
-    if (res && ((res_ld % 4) != 0 || (res_bs % 4) != 0)) return hipErrorInvalidValue;
-    const int ns = (HW + 159) / 160, per = (HW + ns - 1) / ns;
-    note_launch("inorm_fapply_kernel", dim3(ns, C / 32, B), dim3(256));
-    hipLaunchKernelGGL(inorm_fapply_kernel, dim3(ns, C / 32, B), dim3(256), 0, s, x, ld, bs, partial, nchunk, eps, res, res_ld, res_bs,
-                       res_stats, out, out_ld, out_bs, HW, C, per);
-    return hipGetLastError();
-}
-
 // ---------------------------------------------------------------------------
 // correlation pyramid: F.avg_pool2d(corr, 2, stride=2) over the (h2,w2) plane of every
 // (b, i) row -- DCEIFlow/core/corr/raft_corr.py:28-30.

@@ -274,13 +274,11 @@ def test_buffer_reassignment_is_picked_up(gpu):
         assert gu.rel_err(f3.cpu(), f1.cpu()) < 1e-6
 
 
-@pytest.mark.parametrize("knob", ["CF_PYRAMID_FUSED", "CF_INORM_FUSED"])
+@pytest.mark.parametrize("knob", ["CF_PYRAMID_FUSED"])
 def test_fused_small_launches_are_bit_identical(gpu, monkeypatch, knob):
     """Launch-count reductions on the dependent chains against the launches they replace, same bits:
     CF_PYRAMID_FUSED -- the one-launch correlation pyramid (levels 1..3 + coords1 init + flag reset, corr_pyramid_kernel) vs the cascade
-    of corr_pool launches (odd map sizes: 23 x 30 -> 11 x 15 -> 5 x 7 -> 2 x 3), with flow_low riding in the last upflow8 launch;
-    CF_INORM_FUSED -- fold of the InstanceNorm partials + normalisation in one launch (inorm_fapply_kernel, encoder stages 2 / 3) vs
-    inorm_final + inorm_apply."""
+    of corr_pool launches (odd map sizes: 23 x 30 -> 11 x 15 -> 5 x 7 -> 2 x 3), with flow_low riding in the last upflow8 launch."""
     H, W, B = 180, 240, 2
     m = build_eiflow(H, W, 3, gpu)
     evs = [wu.synth_events(B, 5, H, W, 40 + i).to(gpu) for i in range(2)]
