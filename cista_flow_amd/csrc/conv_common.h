@@ -240,8 +240,12 @@ struct EpiAux {
     f32x4 a0, a1, a2, a3;     // aux0 | aux1 | aux2 or addend | second half of aux0 (LSTC forget gate)
 };
 
+// CF_STORE_AUX: cache policy of the fused epilogue's output stores (gfx950 buffer instructions: 1 = sc0, 2 = nt, 16 = sc1 = write-through).
+#ifndef CF_STORE_AUX
+#define CF_STORE_AUX 0
+#endif
 __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned off, f32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, CF_STORE_AUX);
 }
 
 // CLS = which aux slots the epilogue kind can touch (so that only those are allocated): 0 none, 1 aux0,
@@ -249,7 +253,7 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned of
 // in flight together: the tail is a chain of dependent global round trips (~0.8 us each under load), so EB = 4
 // leaves one exposed latency per sub-tile instead of four.
 __device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned off, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, CF_STORE_AUX);
 }
 
 // it0 / it1: which of the lane's four quads (pixel rows (lane >> 3) + 8 it) to finish; nparts / pstride: the patch is the

@@ -4,7 +4,7 @@ import os
 import sys
 import time
 
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from cista_flow_amd.utils.flow_utils import FrameWarp
 
