@@ -94,6 +94,26 @@ def test_eiflow_golden_sequence(gpu, name, mode):
             prev = I.clone()
 
 
+def test_eiflow_batch8_reference_golden(gpu):
+    """Every slot of a B = 8 batch of DIFFERENT sequences (the batch of BASELINE configs[1]) against the reference itself, three
+    recurrent frames at 100x124 (tools/gen_golden.py::run_eiflow_batch8; strided probes, inputs regenerated from the seed)."""
+    g = gu.load("eiflow_100x124_B8.npz")
+    H, W, B, frames, seed = [int(v) for v in g["meta"]]
+    assert B == 8
+    m = build_eiflow(H, W, seed, gpu, "forward")
+    states, prev = None, torch.zeros(B, 1, H, W, device=gpu)
+    with torch.no_grad():
+        for t in range(frames):
+            ev = wu.synth_events(B, 5, H, W, seed * 1000 + t).to(gpu)
+            I, bf, states = m({"event_voxel": ev, "rec_img0": prev}, states, {})
+            for b in range(B):          # slot by slot: an error confined to one slot cannot hide in the batch's scale
+                assert gu.rel_err(I.cpu()[b:b + 1, :, ::2, ::2], g["I_%d" % t][b:b + 1]) < TOL, (t, b)
+                assert gu.rel_err(bf["flow_final"].cpu()[b:b + 1, :, ::2, ::2], g["flow_%d" % t][b:b + 1]) < TOL, (t, b)
+                assert gu.rel_err(gu.sub(states[1].cpu(), 4, 3, 3)[b:b + 1], g["z_%d" % t][b:b + 1]) < TOL, (t, b)
+                assert gu.rel_err(gu.sub(states[2][0].cpu(), 4, 3, 3)[b:b + 1], g["h_%d" % t][b:b + 1]) < TOL, (t, b)
+            prev = I.clone()
+
+
 def test_eraft_golden_sequence(gpu):
     """cista-eraft (BASELINE configs[2]) with the driver's evs_old carry (test_with_flow.py:144-149)."""
     from cista_flow_amd.e2v.e2v_model import ERAFTCistaNet

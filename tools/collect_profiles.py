@@ -31,7 +31,7 @@ def main():
             f.write("%-100s %8s %12.3f %10.2f %7s\n" % (r["Name"][:100], r["Calls"], float(r["TotalDurationNs"]) / 1e6,
                                                        float(r["AverageNs"]) / 1e3, r["Percentage"]))
     shutil.copy(os.path.join(src, "layers.txt"), os.path.join(dst, tag + "_launch_sites_hip_events.txt"))
-    for name in ("ktrace_serial.txt", "stamps.txt", "mfma_clock_probe.txt"):
+    for name in ("ktrace_serial.txt", "stamps.txt", "mfma_clock_probe.txt", "setup_launches.txt"):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(dst, tag + "_" + name))
     shutil.copy(os.path.join(src, "hbm_traffic.json"), os.path.join(dst, "hbm_traffic.json"))

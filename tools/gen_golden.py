@@ -536,6 +536,32 @@ def run_chain(ref_model, name):
     print(name, [out["rec_%d" % t] for t in range(frames)], out["flowm_3"])
 
 
+
+def run_eiflow_batch8(ref_model, name):
+    """Round 4: a reference-run fixture at the BATCH of BASELINE configs[1] -- cista-eiflow, B = 8 different sequences,
+    three recurrent frames at 100x124 -- so that every batch slot of the HIP path is held against the reference itself (the full-size
+    B = 8 / 16 tests compare slots 0 and B - 1 with the oracle and the rest through bit-equality properties).  Inputs are regenerated
+    from the seed by the test; outputs are strided probes of every slot."""
+    from weights_util import fill_module, synth_events
+    H, W, B, frames, seed = 100, 124, 8, 3, 27
+    torch.manual_seed(0)
+    model = ref_model.DCEIFlowCistaNet(ns(H, W, "forward")).eval()
+    fill_module(model, seed)
+    out = {"meta": np.array([H, W, B, frames, seed], dtype=np.int64)}
+    states, prev = None, torch.zeros(B, 1, H, W)
+    with torch.no_grad():
+        for t in range(frames):
+            ev = synth_events(B, 5, H, W, seed * 1000 + t)
+            I, bf, states = model({"event_voxel": ev, "rec_img0": prev}, states, {})
+            out["I_%d" % t] = I.numpy()[:, :, ::2, ::2]
+            out["flow_%d" % t] = bf["flow_final"].numpy()[:, :, ::2, ::2]
+            out["z_%d" % t] = sub(states[1], 4, 3, 3)
+            out["h_%d" % t] = sub(states[2][0], 4, 3, 3)
+            prev = I.clone()
+    np.savez_compressed(os.path.join(GOLD, name), **out)
+    print(name, {k: v.shape for k, v in out.items() if k.endswith("_0")})
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ref_model, ref_flow = import_reference()
@@ -559,6 +585,7 @@ def main():
         return
     if "--only-r4" in sys.argv:        # round 4 addition only (earlier fixtures stay byte-identical)
         run_chain(ref_model, "chain_eiflow_100x124.npz")
+        run_eiflow_batch8(ref_model, "eiflow_100x124_B8.npz")
         return
     if "--only-r3" in sys.argv:        # round 3 additions only (earlier fixtures stay byte-identical)
         run_r3(ref_model)
@@ -582,6 +609,7 @@ def main():
     run_readers("readers.npz")
     run_r3(ref_model)
     run_chain(ref_model, "chain_eiflow_100x124.npz")
+    run_eiflow_batch8(ref_model, "eiflow_100x124_B8.npz")
 
 
 def run_fullsize(ref_model, kind, H, W, frames, seed, name, st, cs):
