@@ -51,9 +51,9 @@ for case in CASES.split(","):
         continue
     if int(tile) in (48, 49):     # conv_wino_p_kernel<0 | 1>: [DMA wait + barrier, items, issue + transform, begin -> first chunk step, chunks (all items), loops, tails, MHz]
         items = d[:, 1].mean().item()
-        print("%-34s tile 4x  %7.1f us %5.1f TF | items per workgroup %4.2f (max %d) | per chunk: dma-wait+barrier %4.0f  issue+transform %4.0f  frag reads + 16 mfma %4.0f"
+        print("%-34s tile %2d  %7.1f us %5.1f TF | items per workgroup %4.2f (max %d) | per chunk: dma-wait+barrier %4.0f  issue+transform %4.0f  frag reads + 16 mfma %4.0f"
               " | begin -> first chunk step %6.0f (once per workgroup)  per item: loop %7.0f  tail + hand-over %6.0f cycles | shader clock %4.0f MHz" % (
-                  shape[0], r[0], r[1], items, int(d[:, 1].max().item()), m[0] / n, m[2] / n, (m[5] - m[0] - m[2]) / n, m[3], m[5] / items, m[6] / items, m[7]), flush=True)
+                  shape[0], int(tile), r[0], r[1], items, int(d[:, 1].max().item()), m[0] / n, m[2] / n, (m[5] - m[0] - m[2]) / n, m[3], m[5] / items, m[6] / items, m[7]), flush=True)
         continue
     if int(tile) == 40:     # conv_wino_kernel: [DMA wait + first barrier, second barrier, issue + input transform]
         print("%-34s tile 40  %7.1f us %5.1f TF | chunks %3d | per chunk: dma-wait+barrier %4.0f  issue+transform %4.0f  barrier %4.0f  "
