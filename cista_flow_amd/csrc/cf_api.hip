@@ -178,6 +178,7 @@ struct cf_handle {
     // replays each descriptor through cf_conv_plan (the same chooser, nothing launched) and compares: a heuristic change is a visible diff
     bool plan_on = false;
     std::vector<std::string> plan_rows;
+    std::string plan_json;          // storage behind cf_plan_json's return value
     hipEvent_t prof_event() {
         if (!prof_pool.empty()) { hipEvent_t e = prof_pool.back(); prof_pool.pop_back(); return e; }
         hipEvent_t e = nullptr;
@@ -1098,8 +1099,8 @@ extern "C" const char* cf_plan_json(cf_handle* h) {
     s += "],\"rows\":[";
     for (size_t i = 0; i < h->plan_rows.size(); ++i) s += (i ? "," : "") + h->plan_rows[i];
     s += "]}";
-    h->prof_report = s;        // (storage that outlives the call; the profile report is rebuilt by every cf_profile_read)
-    return h->prof_report.c_str();
+    h->plan_json = s;
+    return h->plan_json.c_str();
 }
 // The launcher's tile choice for one descriptor (desc: cf_plan_json's `fields` order, n entries), nothing launched, no GPU needed:
 // returns CF_OK and the tile kind launch_conv would take, or CF_ERR_ARG where it would reject the descriptor.

@@ -449,12 +449,6 @@ int wino_p_walkers(const ConvParams& p, long NR, int pipe) {
     if (R < 1) R = 1;
     const long per_xcd = (NR + 7) / 8;
     if (R > per_xcd) R = per_xcd;
-    // same number of rounds with fewer walkers: every walker then carries (nearly) the same number of items
-    static const int even = getenv("CF_WINOP_EVEN") ? atoi(getenv("CF_WINOP_EVEN")) : 0;
-    if (even) {
-        const long rounds = (per_xcd + R - 1) / R;
-        R = (per_xcd + rounds - 1) / rounds;
-    }
     return (int)R;
 }
 
