@@ -1659,7 +1659,8 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
     // (tools/r4_winop.sh): with four workgroups resident per CU the hardware dispatcher already starts a fresh workgroup's prologue
     // beside the other three's MFMAs, which is all the walk buys.  CF_WINOP=1 turns it on.
     if (auto_tile && tile == 40 && wino_p_ok(p)) {
-        static const int winop = getenv("CF_WINOP") ? atoi(getenv("CF_WINOP")) : 0;
+        const char* ew = getenv("CF_WINOP");               // read per launch: the model-level bit-identity test flips it
+        const int winop = ew ? atoi(ew) : 0;
         if (winop) tile = winop == 2 ? 49 : 48;
     }
     if (tile == 0) {

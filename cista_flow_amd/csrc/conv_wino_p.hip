@@ -268,7 +268,12 @@ __global__ __launch_bounds__(256, PIPE ? 3 : 4) void conv_wino_p_kernel(const Co
         st_wait += t1 - t0;
 #endif
         WP_SLOT(1, 0, WP_DMA(0));
-        WP_SLOT(1, 1, WP_DMA(1); bu[0] = buf_load4(u_rsrc, uoff, u_next));
+        WP_SLOT(1, 1, WP_DMA(1));
+        // (a slot of its own: inside one slot the compiler is free to put this load BETWEEN the two DMA pieces, and the vmcnt(4) at the
+        // top of the next step -- "the two raw pieces are the oldest two of six" -- then no longer covers the second piece: a race that
+        // the single-operator tests did not show and the model's determinism soak did, r04)
+        bu[0] = buf_load4(u_rsrc, uoff, u_next);
+        __builtin_amdgcn_sched_barrier(0);
         WP_SLOT(1, 2, WP_RD(0));
         WP_SLOT(1, 3, bu[1] = buf_load4(u_rsrc, uoff + 1024u, u_next));
         WP_SLOT(2, 0, WP_T(0); WP_RD(1));

@@ -294,6 +294,36 @@ def test_buffer_reassignment_is_picked_up(gpu):
         assert gu.rel_err(f3.cpu(), f1.cpu()) < 1e-6
 
 
+@pytest.mark.parametrize("winop", ["1", "2"])
+def test_persistent_winograd_in_the_model_is_bit_identical(gpu, monkeypatch, winop):
+    """conv_wino_p_kernel<0 | 1> (tiles 48 / 49, CF_WINOP=1 | 2) compute conv_wino_kernel's arithmetic bit for bit, so the WHOLE recurrent
+    model must reproduce the default run exactly -- at the headline geometry, where the walkers carry several items, the layers have two
+    and three channel segments and every fused epilogue is in play, over enough frames that a hand-off race shows (r04: a VMEM issue-order
+    race in the pipelined variant passed every single-operator test and failed here)."""
+    H, W, B = 180, 240, 4
+    m = build_eiflow(H, W, 5, gpu)
+    evs = [wu.synth_events(B, 5, H, W, 300 + i).to(gpu) for i in range(4)]
+
+    def run(n):
+        prev, st, res = torch.zeros(B, 1, H, W, device=gpu), None, []
+        with torch.no_grad():
+            for t in range(n):
+                I, bf, st = m({"event_voxel": evs[t % 4], "rec_img0": prev}, st, {})
+                prev = I
+                res.append((I.clone(), bf["flow_final"].clone(), st[1].clone(), st[2][0].clone()))
+        torch.cuda.synchronize()
+        return res
+
+    monkeypatch.delenv("CF_WINOP", raising=False)
+    ref = run(24)
+    monkeypatch.setenv("CF_WINOP", winop)
+    got = run(24)
+    monkeypatch.delenv("CF_WINOP", raising=False)
+    for t, (a, b) in enumerate(zip(ref, got)):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y), t
+
+
 @pytest.mark.parametrize("knob", ["CF_PYRAMID_FUSED"])
 def test_fused_small_launches_are_bit_identical(gpu, monkeypatch, knob):
     """Launch-count reductions on the dependent chains against the launches they replace, same bits:
