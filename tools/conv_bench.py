@@ -60,6 +60,9 @@ def run(shape, tile, iters=20):
     x = torch.randn(B, H, W, Cin, device=dev)
     w = torch.randn(Cout, Cin, KH, KW, device=dev) / (Cin * KH * KW) ** 0.5
     b = torch.randn(Cout, device=dev)
+    z = os.environ.get("ZERO", "")   # DVFS probe: all-zero operands draw less power (MI355X_MICROARCH.md, DVFS give-back item 1)
+    if z in ("1", "x"): x.zero_()    # ZERO=1: everything, ZERO=x: activations only, ZERO=w: weights only
+    if z in ("1", "w"): w.zero_(); b.zero_()
     Ho = (H + 2 * pT - KH) // stride + 1
     Wo = (W + 2 * pL - KW) // stride + 1
     out = torch.empty(B, Ho, Wo, Cout, device=dev)
