@@ -2098,7 +2098,7 @@ static int op_conv2d_impl(const float* in, int B, int Cin, int H, int W, const f
         p.w_wino = static_cast<float*>(wino.p);
     }
     TmpBuf wino16;
-    if (tile == 47 && !gather && KH == 3 && KW == 3) {
+    if ((tile == 47 || tile == 50) && !gather && KH == 3 && KW == 3) {
         if (hipMalloc(&wino16.p, sizeof(float) * (size_t)wino16_weight_floats(Cout, pc.cin_pad)) != hipSuccess) return CF_ERR_HIP;
         if (launch_wino16_weights(pc.w, static_cast<float*>(wino16.p), Cout, pc.cin_pad, st) != hipSuccess) return CF_ERR_HIP;
         p.w_wino16 = static_cast<float*>(wino16.p);

@@ -140,7 +140,7 @@ hipError_t launch_wino16_weights(const float* w, float* u, int rows, int cin_pad
 long wino16_weight_floats(int rows, int cin_pad);
 bool wino16_ok(const ConvParams& p);
 int wino16_regions(int Ho, int Wo);
-hipError_t launch_wino16(const ConvParams& p, int batch, hipStream_t s);
+hipError_t launch_wino16(const ConvParams& p, int batch, hipStream_t s, bool deep = false);    // deep: conv_wino16_kernel<1> (tile 50)
 // conv_wino_p.hip, reached through launch_conv (tile 48): conv_wino_kernel's arithmetic in persistent workgroups that walk several regions
 bool wino_p_ok(const ConvParams& p);
 int wino_p_walkers(const ConvParams& p, long NR, int pipe = 0);

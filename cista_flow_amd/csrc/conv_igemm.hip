@@ -1227,7 +1227,7 @@ static int wino_regions(int Ho, int Wo) {
 int conv_stats_chunks(const ConvParams& p, int tile) {
     if (tile == 40 || tile == 44 || tile == 45 || tile == 48 || tile == 49) return wino_regions(p.Ho, p.Wo) * 4;
     if (tile == 42) return wino4_regions(p.Ho, p.Wo) * 16;
-    if (tile == 47) return wino16_regions(p.Ho, p.Wo) * 2;
+    if (tile == 47 || tile == 50) return wino16_regions(p.Ho, p.Wo) * 2;
     return (p.Ho * p.Wo + 31) / 32;
 }
 
@@ -1499,6 +1499,7 @@ const char* conv_tile_name(int tile) {
         case 42: return "conv_wino4_kernel";
         case 46: return "conv_wino1d_kernel";
         case 47: return "conv_wino16_kernel";
+        case 50: return "conv_wino16_kernel<deep>";
         case 48: return "conv_wino_p_kernel<0>";
         case 49: return "conv_wino_p_kernel<1>";
         case 44: return "conv_wino_sk_kernel<2>";
@@ -1512,7 +1513,7 @@ const char* conv_tile_name(int tile) {
 // direct kernels.  bench.py prices the executed-MFMA roofline fraction with it (per launch-site row, not by kernel-name prefix).
 double conv_tile_mfma_ratio(int tile) {
     switch (tile) {
-        case 40: case 44: case 45: case 47: case 48: case 49: return 4.0 / 9.0;
+        case 40: case 44: case 45: case 47: case 48: case 49: case 50: return 4.0 / 9.0;
         case 46: return 0.6;
         case 42: return 0.25;
         default: return 1.0;
@@ -1636,14 +1637,20 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
         const long wg = (long)wino_regions(p.Ho, p.Wo) * ((p.cout + 31) / 32) * tb;
         const long wg16 = (long)wino16_regions(p.Ho, p.Wo) * ((p.cout + 31) / 32) * tb;
         static const long sk2_max = getenv("CF_WINO_SK2_MAX") ? atol(getenv("CF_WINO_SK2_MAX")) : 256;
-        static const long w16min = getenv("CF_WINO16_MIN") ? atol(getenv("CF_WINO16_MIN")) : 96;
+        // 24: the smallest launch measured (r04, B = 1 at 180x240: convf2 24 workgroups 16.7 -> 12.5 us, menc 48: 29.8 -> 23.8, convc2 72:
+        // 25.7 -> 20.0; the step at B = 1 / 2: +5 % / +3.5 % together with CF_WINO1D_MIN below, tools/r4_small.sh); was 96
+        static const long w16min = getenv("CF_WINO16_MIN") ? atol(getenv("CF_WINO16_MIN")) : 24;
         if (tile == 40 && wg > sk2_max && wg <= wino16_max()) tile = 47;
         else if (tile == 0 && wg16 >= w16min) tile = 47;
+        // at most ONE workgroup per CU: the deep-prefetch / software-pipelined instantiation (tile 50, bit-identical), see conv_wino16.hip
+        const char* ed = getenv("CF_WINO16_DEEP_MAX");      // read per launch: tests flip it
+        const long deep_max = ed ? atol(ed) : 400;
+        if (tile == 47 && wg16 <= deep_max) tile = 50;
     }
     // 1x5 / 5x1 layers with transformed weights (the separable GRU): one-dimensional Winograd F(2,5), 1.67x fewer MFMAs (conv_wino1d.hip)
     if (tile == 0 && wino1d_ok(p)) {
         const long tb = p.tile_batch > 0 ? p.tile_batch : batch;
-        static const long w1min = getenv("CF_WINO1D_MIN") ? atol(getenv("CF_WINO1D_MIN")) : 128;
+        static const long w1min = getenv("CF_WINO1D_MIN") ? atol(getenv("CF_WINO1D_MIN")) : 44;      // B = 1: 88 (z, r) / 44 (q) workgroups, 16.7 -> 14.6 us each; was 128
         if (wino1d_workgroups(p, tb) >= w1min) tile = 46;
     }
     // F(4x4,3x3) (tile 42): 1.78x fewer MFMAs again, in workgroups of 512 output pixels x 32 channels -- taken when the launch
@@ -1714,7 +1721,7 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
                 tile = wgs128x128 >= 2304 ? 25 : ((p.cout >= 256 && p.cout % 128 == 0) ? 28 : 23);
         }
     }
-    if (((tile >= 20 && tile <= 40) || tile == 42 || tile == 44 || tile == 45 || tile == 47 || tile == 48 || tile == 49) && !(p.a_mode == A_NHWC && dma_range_ok(p))) return hipErrorInvalidValue;
+    if (((tile >= 20 && tile <= 40) || tile == 42 || tile == 44 || tile == 45 || tile == 47 || tile == 48 || tile == 49 || tile == 50) && !(p.a_mode == A_NHWC && dma_range_ok(p))) return hipErrorInvalidValue;
     if (tile_used) *tile_used = tile;
     g_last_launch.kernel = conv_tile_name(tile);
     if (p.prec != 0 && p.prec != 1 && p.prec != 3) return hipErrorInvalidValue;
@@ -1760,6 +1767,7 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
         case 42: return launch_wino4(p, batch, s);
         case 46: return launch_wino1d(p, batch, s);
         case 47: return launch_wino16(p, batch, s);
+        case 50: return launch_wino16(p, batch, s, true);
         case 48: return launch_wino_p(p, batch, s, 0);
         case 49: return launch_wino_p(p, batch, s, 1);
         case 44: return wino_ok(p) ? launch_wino_sk(p, batch, s, 2) : hipErrorInvalidValue;

@@ -16,6 +16,16 @@
 //           lane and position, a chunk ahead;
 //   tail    as conv_wino_kernel: j direction in registers, i direction across the waves through LDS, then the 64 x 32 output block as two
 //           32-row patches through the common fused epilogue (wave w finishes 16 rows of patch w & 1).
+//
+// DEEP = 1 (tile 50, round 4): the same arithmetic for launches that put at most ONE workgroup on a CU (B = 1 / 2 at 1/8 resolution: 24-144
+// workgroups).  There a wave has its SIMD to itself and nothing hides what the plain loop leaves exposed: the stamps of the plain kernel at
+// B = 1 (profiles/r04_small_batch.txt) say 1094 cycles per chunk for 512 cycles of MFMAs with the raw patch long landed (50 cycles of wait) --
+// the U loads issued one chunk (~1100 cycles = 470 ns at the 2.33 GHz these launches hold) ahead are an L2 round trip ahead, no more, and the 16
+// ds_read_b32 + the transform sit in front of the first MFMA.  So: U TWO chunks ahead (two register sets, the chunk loop unrolled by two), the raw
+// patch three chunks ahead (ring of four = the 16 KB the exchange buffer has anyway), and a software-pipelined A side -- step k reads raw(k + 1) and
+// builds chunk k + 1's operands between the MFMAs of chunk k.  ~125 registers more than matter at four workgroups per CU (11.2 of DESIGN.md: the
+// pipelined loop alone bought nothing at B = 8), which is why it is a separate instantiation with launch_bounds(256, 2).
+// Bit-identical to DEEP = 0 (same products, same accumulation order): tests/test_ops_gpu.py.
 #include "conv_common.h"
 
 namespace cf {
@@ -26,15 +36,16 @@ static constexpr int W6_RAW = 2 * W6_PLANE * 4;             // floats per raw bu
 static constexpr int W6_UV = 16 * 64 * 4;                   // floats of a chunk's U block (4096: 16 pos x 32 n x 8 k)
 static constexpr int W6_X = 4 * 2 * 16 * 32;                // floats of the exchange buffer (16 KB)
 
-__global__ __launch_bounds__(256, 4) void conv_wino16_kernel(const ConvParams p) {
-    static_assert(2 * W6_RAW <= W6_X && 2 * 32 * EPI_S <= W6_X, "raw ring and the two epilogue patches overlay the exchange buffer");
+template <int DEEP>
+__global__ __launch_bounds__(256, DEEP ? 2 : 4) void conv_wino16_kernel(const ConvParams p) {
+    static_assert(4 * W6_RAW <= W6_X && 2 * 32 * EPI_S <= W6_X, "raw ring (two buffers, four when DEEP) and the two epilogue patches overlay the exchange buffer");
     __shared__ __attribute__((aligned(16))) float smem[W6_X + 64];       // ONE __shared__ object (see conv_wino_kernel)
     float* const sRaw = smem;
     int* const sMtab = reinterpret_cast<int*>(smem + W6_X);
 #ifdef CF_STAMP
     const long long t_begin = __builtin_readcyclecounter();
     const long long r_begin = (long long)__builtin_amdgcn_s_memrealtime();
-    long long st_wait = 0;
+    long long st_wait = 0, t_loop_begin = 0, t_loop_end = 0;
 #endif
 
     const int tid = threadIdx.x;
@@ -113,6 +124,163 @@ __global__ __launch_bounds__(256, 4) void conv_wino16_kernel(const ConvParams p)
     const int rd_a = (cell0 + ra * 10) * 4 + kk, rd_b = (cell0 + rb * 10) * 4 + kk;      // floats; + quad plane s * 512, + column cell * 4
     const unsigned uoff = (unsigned)((wave * 4) * 64 + lane) * 16u;         // + j KiB: position (wave, j) of a chunk's U block
 
+    if constexpr (DEEP) {
+        // ---- U two chunks ahead, raw three chunks ahead (ring of four), A operands of chunk k + 1 built between the MFMAs of chunk k ----
+        // ONE wave per SIMD issues in order: whatever is not placed BETWEEN two MFMAs runs while the matrix pipe idles (the first deep
+        // version, MFMAs in blocks of four and everything else in front of them: 968 cycles per chunk for 512 of MFMA).  So a step is sixteen
+        // hand-placed slots, one MFMA each, fenced by sched_barriers: slot 0 / 1 the raw DMA of chunk k + 3 (offset, then the request),
+        // 2..5 the sixteen LDS reads of raw(k + 1), 6 / 7 the segment iterator, 10..13 the transform (reads long back), U(k + 2) for position j
+        // behind j's last MFMA.  The segment iterator is branch-free here (selects over three precomputed descriptors): a branch would end the
+        // scheduling region in the middle of the slots.
+        // (pick(): by-value arguments -- `c ? x : y` of two captured variables is an LVALUE conditional, i.e. a select of two ADDRESSES inside the
+        // closure object, which keeps the closure, every variable it captures and a copy of the parameter block in scratch)
+        auto pick = [](bool c, auto x, auto y) __attribute__((always_inline)) { return c ? x : y; };
+        const int nseg = p.nseg;
+        const float* const sb1 = nseg > 1 ? p.in[1] + (long)b * p.seg_bs[1] : seg_base;
+        const float* const sb2 = nseg > 2 ? p.in[2] + (long)b * p.seg_bs[2] : seg_base;
+        const int ld1 = p.seg_ld[1], ld2 = p.seg_ld[2], cn1 = p.seg_c[1], cn2 = p.seg_c[2];
+        auto advance = [&]() __attribute__((always_inline)) {
+            it_cs += W6_KC;
+            const bool adv = it_cs >= seg_cn;
+            it_cs = pick(adv, 0, it_cs);
+            it_seg += pick(adv, 1, 0);
+            const bool upd = adv && it_seg < nseg;
+            const bool one = it_seg == 1;
+            seg_base = pick(upd, pick(one, sb1, sb2), seg_base);
+            seg_ld = pick(upd, pick(one, ld1, ld2), seg_ld);
+            seg_cn = pick(upd, pick(one, cn1, cn2), seg_cn);
+        };
+        auto raw_off = [&](bool live) __attribute__((always_inline)) {
+            return (a_pix < 0 || !live) ? BUF_OOB : (unsigned)a_pix * ((unsigned)seg_ld * 4u) + a_q;
+        };
+        auto raw_dma = [&](int buf, unsigned off) __attribute__((always_inline)) {
+            dma16_to_lds(make_rsrc(seg_base), sRaw + buf * W6_RAW + 64 * wave * 4, off, (unsigned)it_cs * 4u);
+        };
+        f32x4 bu[2][4];
+        float afc[4][2];                                // A operands of the chunk whose MFMAs run in this step
+        auto transform = [&](const float (&t)[2][4], float (&af)[4][2]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                af[0][s] = t[s][0] - t[s][2];
+                af[1][s] = t[s][1] + t[s][2];
+                af[2][s] = t[s][2] - t[s][1];
+                af[3][s] = t[s][1] - t[s][3];
+            }
+        };
+        auto load_u = [&](int chunk, f32x4 (&dst)[4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dst[j] = buf_load4(u_rsrc, uoff + 1024u * j, (unsigned)chunk * (W6_UV * 4u));
+        };
+#define W6_FENCE __builtin_amdgcn_sched_barrier(0)
+#define W6_PIN(x) asm volatile("" : "+v"(x))
+        // MFMA m of a step: position m >> 2; within a position the two accumulators alternate (a0 b0 | a0 b2 | a1 b1 | a1 b3)
+#define W6_MFMA(m)                                                                                                                          \
+        acc[(m) >> 2][(m) & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(afc[(m) >> 2][((m) >> 1) & 1], u[(m) >> 2][(((m) & 1) << 1) | (((m) >> 1) & 1)], \
+                                                                      acc[(m) >> 2][(m) & 1], 0, 0, 0)
+        // raw values of patch column c (both rows) of k-step s: two LDS reads
+#define W6_RD(s_, c_)                                                                                                   \
+        {                                                                                                               \
+            const int col = (((c_) >> 1) + ((c_) & 1) * 5) * 4 + (s_) * (W6_PLANE * 4);                                 \
+            va[s_][c_] = r[rd_a + col];                                                                                 \
+            vb[s_][c_] = r[rd_b + col];                                                                                 \
+        }
+        // in flight at the top of step k, oldest first: raw(k+1) | U(k) x 4 | raw(k+2) | U(k+1) x 4 (the prologue's order differs, its count
+        // does not): raw(k+1) has landed once at most NINE are outstanding
+        auto deep_step = [&](int k, f32x4 (&u)[4]) __attribute__((always_inline)) {
+#ifdef CF_STAMP
+            const long long t0 = __builtin_readcyclecounter();
+#endif
+            asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            raw_barrier();                              // raw(k+1) has landed for everybody; everybody has read raw(k) (in step k - 1)
+#ifdef CF_STAMP
+            st_wait += __builtin_readcyclecounter() - t0;
+#endif
+            const float* r = sRaw + ((k + 1) & 3) * W6_RAW;
+#ifdef W6_EXP_U0
+            const unsigned u_next = 0;                  // experiment: every U load hits the same 16 KB (is the loop waiting for U?)
+#else
+            const unsigned u_next = (unsigned)(k + 2 < nchunk ? k + 2 : k) * (W6_UV * 4u);      // past the end: a harmless re-load
+#endif
+            float va[2][4], vb[2][4], t[2][4], afn[4][2];
+            W6_FENCE;
+            W6_MFMA(0);  unsigned off = raw_off(k + 3 < nchunk); W6_PIN(off);                                   W6_FENCE;
+            W6_MFMA(1);  raw_dma((k + 3) & 3, off);             /* over raw(k-1), read in step k - 2 */         W6_FENCE;
+            W6_MFMA(2);  W6_RD(0, 0); W6_RD(0, 2);                                                              W6_FENCE;
+            W6_MFMA(3);  W6_RD(0, 1); W6_RD(0, 3);                                                              W6_FENCE;
+            u[0] = buf_load4(u_rsrc, uoff, u_next);             /* raw(k+3) before U(k+2) in issue order */     W6_FENCE;
+            W6_MFMA(4);  W6_RD(1, 0); W6_RD(1, 2);                                                              W6_FENCE;
+            W6_MFMA(5);  W6_RD(1, 1); W6_RD(1, 3);                                                              W6_FENCE;
+            W6_MFMA(6);  advance();                                                                             W6_FENCE;
+            W6_MFMA(7);                                                                                         W6_FENCE;
+            u[1] = buf_load4(u_rsrc, uoff + 1024u, u_next);                                                     W6_FENCE;
+            W6_MFMA(8);                                                                                         W6_FENCE;
+            W6_MFMA(9);                                                                                         W6_FENCE;
+            W6_MFMA(10);                                                                                        W6_FENCE;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { t[0][c] = __builtin_fmaf(sgn, vb[0][c], va[0][c]); W6_PIN(t[0][c]); }      // row `wave` of B^T d
+            W6_FENCE;
+            W6_MFMA(11);                                                                                        W6_FENCE;
+            u[2] = buf_load4(u_rsrc, uoff + 2048u, u_next);                                                     W6_FENCE;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { t[1][c] = __builtin_fmaf(sgn, vb[1][c], va[1][c]); W6_PIN(t[1][c]); }
+            W6_FENCE;
+            W6_MFMA(12);                                                                                        W6_FENCE;
+            transform(t, afn);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { W6_PIN(afn[j][0]); W6_PIN(afn[j][1]); }
+            W6_FENCE;
+            W6_MFMA(13);                                                                                        W6_FENCE;
+            W6_MFMA(14);                                                                                        W6_FENCE;
+            W6_MFMA(15);                                                                                        W6_FENCE;
+            u[3] = buf_load4(u_rsrc, uoff + 3072u, u_next);                                                     W6_FENCE;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) afc[j][s] = afn[j][s];
+        };
+        {
+            raw_dma(0, raw_off(true));
+            advance();
+            raw_dma(1, raw_off(1 < nchunk));
+            advance();
+            raw_dma(2, raw_off(2 < nchunk));
+            advance();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        load_u(0, bu[0]);
+        load_u(1 < nchunk ? 1 : 0, bu[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // raw(0): everything behind it is raw(1), raw(2), 8 U loads
+        raw_barrier();
+        {
+            const float* r = sRaw;
+            float va[2][4], vb[2][4], t[2][4];
+            W6_RD(0, 0); W6_RD(0, 1); W6_RD(0, 2); W6_RD(0, 3);
+            W6_RD(1, 0); W6_RD(1, 1); W6_RD(1, 2); W6_RD(1, 3);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) t[s][c] = __builtin_fmaf(sgn, vb[s][c], va[s][c]);
+            transform(t, afc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef CF_STAMP
+        t_loop_begin = __builtin_readcyclecounter();
+#endif
+        int k = 0;
+        for (; k + 1 < nchunk; k += 2) {
+            deep_step(k, bu[0]);
+            deep_step(k + 1, bu[1]);
+        }
+        if (k < nchunk) deep_step(k, bu[0]);
+#ifdef CF_STAMP
+        t_loop_end = __builtin_readcyclecounter();
+#endif
+#undef W6_FENCE
+#undef W6_PIN
+#undef W6_MFMA
+#undef W6_RD
+    } else {
     f32x4 bu[4];
     auto chunk_step = [&](int k) __attribute__((always_inline)) {
         // in flight, oldest first: the raw(k) piece, then the four U(k) loads
@@ -162,12 +330,14 @@ __global__ __launch_bounds__(256, 4) void conv_wino16_kernel(const ConvParams p)
     for (int j = 0; j < 4; ++j) bu[j] = buf_load4(u_rsrc, uoff + 1024u * j, 0);
     __builtin_amdgcn_sched_barrier(0);
 #ifdef CF_STAMP
-    const long long t_loop_begin = __builtin_readcyclecounter();
+    t_loop_begin = __builtin_readcyclecounter();
 #endif
     for (int k = 0; k < nchunk; ++k) chunk_step(k);
 #ifdef CF_STAMP
-    const long long t_loop_end = __builtin_readcyclecounter();
+    t_loop_end = __builtin_readcyclecounter();
 #endif
+
+    }
 
     // the last chunk step's dead past-the-end DMA (zeros into the ring) must have landed before anything overlays the ring: an explicit
     // wait, so that this does not rest on the compiler's LDS-DMA bookkeeping in front of the barrier
@@ -275,12 +445,13 @@ bool wino16_ok(const ConvParams& p) {
     return dma_range_ok(p);
 }
 
-hipError_t launch_wino16(const ConvParams& p, int batch, hipStream_t s) {
+hipError_t launch_wino16(const ConvParams& p, int batch, hipStream_t s, bool deep) {
     if (!wino16_ok(p)) return hipErrorInvalidValue;
     const long wgs = (long)wino16_regions(p.Ho, p.Wo) * ((p.cout + 31) / 32) * batch;
     if (wgs <= 0 || wgs >= 0x7FFFFFFFL) return hipErrorInvalidValue;
     g_last_launch.threads = wgs * 256;
-    hipLaunchKernelGGL(conv_wino16_kernel, dim3((unsigned)wgs), dim3(256), 0, s, p);
+    if (deep) hipLaunchKernelGGL(conv_wino16_kernel<1>, dim3((unsigned)wgs), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(conv_wino16_kernel<0>, dim3((unsigned)wgs), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 

@@ -152,6 +152,8 @@ STATS_CASES = [
     (96, 96, 3, 3, 1, 1, 0, 49, 21, 37),
     (96, 128, 3, 3, 1, 1, 0, 47, 13, 19),    # conv_wino16_kernel: two statistics patches per 8 x 8 region, ragged
     (64, 64, 3, 3, 1, 1, 0, 47, 24, 32),
+    (96, 128, 3, 3, 1, 1, 0, 50, 13, 19),    # ... deep-prefetch instantiation
+    (64, 64, 3, 3, 1, 1, 0, 50, 24, 32),
 ]
 
 
@@ -247,6 +249,8 @@ def test_conv_winograd(gpu, case):
     assert (g16 - ref).abs().max().item() < 1e-4
     assert (g16 - got).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
     assert torch.equal(g16, run_conv(gpu, x, w, b, 1, 1, 1, pad_mode, 0, epi, 47, H, W))
+    # ... and its deep-prefetch / software-pipelined instantiation for launches of at most one workgroup per CU (tile 50): bit for bit
+    assert torch.equal(run_conv(gpu, x, w, b, 1, 1, 1, pad_mode, 0, epi, 50, H, W), g16)
 
 
 WINO4_CASES = WINO_CASES + [(64, 64, 1, 96, 128, 1), (128, 64, 1, 37, 50, 0), (16, 40, 0, 12, 12, 0), (80, 32, 1, 16, 32, 0),

@@ -127,7 +127,7 @@ def test_traffic_table_uses_the_library_kernel_names():
     import json
     from cista_flow_amd import lib
     L = lib.load()
-    names = {L.cf_conv_tile_name(t).decode() for t in range(1, 50)}
+    names = {L.cf_conv_tile_name(t).decode() for t in range(1, 51)}
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     table = json.load(open(os.path.join(root, "profiles", "hbm_traffic.json")))
     conv = [k for k in table if k.startswith("conv_dma_kernel") or k.startswith("conv_igemm_kernel")]

@@ -24,7 +24,40 @@ CONFIGS = [  # name, class, H, W, B   (BASELINE.json configs[1..4]: per-GPU shap
 ]
 
 
+def write_table(out, fields):
+    path = os.path.join(ROOT, "tests", "golden", "kernel_selection.json")
+    with open(path, "w") as f:
+        f.write("{\n \"_meta\": %s,\n \"fields\": %s,\n \"configs\": {\n" % (json.dumps(out["_meta"]), json.dumps(fields)))
+        names = list(out["configs"])
+        for i, n in enumerate(names):
+            f.write("  %s: [\n" % json.dumps(n))
+            rows = out["configs"][n]
+            for j, r in enumerate(rows):
+                f.write("   %s%s\n" % (json.dumps(r, separators=(",", ":")), "," if j + 1 < len(rows) else ""))
+            f.write("  ]%s\n" % ("," if i + 1 < len(names) else ""))
+        f.write(" }\n}\n")
+    print("wrote", path)
+
+
+def replay():
+    """--replay (CPU): keep the recorded descriptors, re-run the launcher's chooser on each and rewrite the choices -- after a change of
+    the heuristics' defaults that does not add or remove launch sites.  Prints every site whose kernel changed."""
+    from cista_flow_amd import lib
+    path = os.path.join(ROOT, "tests", "golden", "kernel_selection.json")
+    with open(path) as f:
+        t = json.load(f)
+    for name, rows in t["configs"].items():
+        for r in rows:
+            tile, kernel = lib.conv_plan(r["desc"])
+            if (tile, kernel) != (r["tile"], r["kernel"]):
+                print("%-20s %-40s %s (tile %d) -> %s (tile %d)" % (name, r["tag"], r["kernel"], r["tile"], kernel, tile))
+                r["tile"], r["kernel"] = tile, kernel
+    write_table(t, t["fields"])
+
+
 def main():
+    if "--replay" in sys.argv:
+        return replay()
     dev = torch.device("cuda:0")
     out = {"_meta": "tools/gen_kernel_table.py: launch-site -> kernel for every BASELINE config (default environment, fp32)", "configs": {}}
     fields = None
@@ -57,18 +90,7 @@ def main():
         print("%-22s %3d launch sites, kernels: %s" % (name, len(rows), sorted({r["kernel"] for r in rows})), flush=True)
         del m, h
     out["fields"] = fields
-    path = os.path.join(ROOT, "tests", "golden", "kernel_selection.json")
-    with open(path, "w") as f:
-        f.write("{\n \"_meta\": %s,\n \"fields\": %s,\n \"configs\": {\n" % (json.dumps(out["_meta"]), json.dumps(fields)))
-        names = list(out["configs"])
-        for i, n in enumerate(names):
-            f.write("  %s: [\n" % json.dumps(n))
-            rows = out["configs"][n]
-            for j, r in enumerate(rows):
-                f.write("   %s%s\n" % (json.dumps(r, separators=(",", ":")), "," if j + 1 < len(rows) else ""))
-            f.write("  ]%s\n" % ("," if i + 1 < len(names) else ""))
-        f.write(" }\n}\n")
-    print("wrote", path)
+    write_table(out, fields)
 
 
 if __name__ == "__main__":
