@@ -196,11 +196,8 @@ __global__ __launch_bounds__(256, DEEP ? 2 : 4) void conv_wino16_kernel(const Co
             st_wait += __builtin_readcyclecounter() - t0;
 #endif
             const float* r = sRaw + ((k + 1) & 3) * W6_RAW;
-#ifdef W6_EXP_U0
-            const unsigned u_next = 0;                  // experiment: every U load hits the same 16 KB (is the loop waiting for U?)
-#else
+            // (with every U load aimed at ONE hot 16 KB block the step took 900 instead of 915 cycles: the loop does not wait for U)
             const unsigned u_next = (unsigned)(k + 2 < nchunk ? k + 2 : k) * (W6_UV * 4u);      // past the end: a harmless re-load
-#endif
             float va[2][4], vb[2][4], t[2][4], afn[4][2];
             W6_FENCE;
             W6_MFMA(0);  unsigned off = raw_off(k + 3 < nchunk); W6_PIN(off);                                   W6_FENCE;

@@ -181,7 +181,11 @@ __global__ __launch_bounds__(256, 4) void conv_wino1d_kernel(const ConvParams p)
     __builtin_amdgcn_sched_barrier(0);
     // (requesting raw and U TWO chunks ahead -- ring of three, two sets of U registers -- measured no faster: 34.8 vs 34.1 us; handing the
     // chunks off in PAIRS -- ring of four, one barrier per two chunks, 48 KB of LDS -- measured slower: 36.0 vs 33.3 us, 1585 vs 1601 frames/s; reading and
-    // transforming chunk k + 1 in the shadow of chunk k's MFMAs -- 119 VGPRs -- measured no faster either: 35.3 us)
+    // transforming chunk k + 1 in the shadow of chunk k's MFMAs -- 119 VGPRs -- measured no faster either: 35.3 us.
+    // r04, for the one-wave-per-SIMD launches of B = 1 / 2 (what conv_wino16_kernel<1> is for the 3x3 layers): U two chunks ahead, ring of four,
+    // pipelined A side, twelve hand-placed MFMA slots, branch-free iterator -- bit-identical, 1362 -> 1196 cycles per chunk for 768 of MFMA, but
+    // 14.8 -> 14.4 us per launch only (prologue +1.5 k cycles) and 33.4 -> 34.5 us at B = 8; spreading the fillers evenly over the slots made it
+    // SLOWER (15.0 us): profiles/r04_small_batch.txt.  Not kept.)
 #ifdef CF_STAMP
     const long long t_loop_begin = __builtin_readcyclecounter();
 #endif
