@@ -7,6 +7,11 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 struct Big { int v[160]; };
 __global__ void empty_kernel(const Big b, int* out) { if (b.v[0] == 12345) out[0] = b.v[1]; }
+__global__ void spin_kernel(long long cycles, int* out) {      // holds the queue while the host enqueues behind it (bounded: exits after `cycles`)
+    const long long t0 = __builtin_readcyclecounter();
+    while (__builtin_readcyclecounter() - t0 < cycles) __builtin_amdgcn_s_sleep(32);
+    if (cycles == 12345) out[0] = 1;
+}
 static double now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int main() {
     int* out; CK(hipMalloc(&out, 64));
@@ -44,7 +49,16 @@ int main() {
         for (int i = 0; i < N; ++i) hipLaunchKernelGGL(empty_kernel, dim3(64), dim3(256), 0, st[0], b, out);
         CK(hipDeviceSynchronize());
         double t8 = now();
+        // GPU-side cost of a dependent kernel: N empty kernels queued BEHIND a 10 ms spin kernel, so the host is out of the picture
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, st[0], 20000000LL, out);
+        CK(hipEventRecord(e0, st[0]));
+        for (int i = 0; i < N; ++i) hipLaunchKernelGGL(empty_kernel, dim3(64), dim3(256), 0, st[0], b, out);
+        CK(hipEventRecord(e1, st[0]));
+        CK(hipDeviceSynchronize());
+        float ms_q = 0; CK(hipEventElapsedTime(&ms_q, e0, e1));
         if (rep == 1) {
+            printf("GPU side, kernels queued behind a spin kernel: %.2f us per dependent empty kernel on one stream\n", ms_q * 1e3 / N);
             printf("launch, one stream (640-byte argument):   %.2f us per call on the host; drained %.2f us per kernel end to end\n", (t1 - t0) / N, (t1b - t0) / N);
             printf("launch, four streams round-robin:         %.2f us per call on the host; drained %.2f us per kernel end to end\n", (t2 - t1b) / N, (t3 - t1b) / N);
             printf("event record + cross-stream wait:         %.2f us per pair on the host\n", (t4 - t3) / N);
