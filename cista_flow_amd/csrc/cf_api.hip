@@ -1945,9 +1945,14 @@ static int step_dispatch(cf_handle* h, const StepArgs& a, bool reuse, hipStream_
         // second sighting of this pointer tuple: capture the step
         int rc = fence_in();
         if (rc != CF_OK) return rc;
-        if (hipStreamBeginCapture(run, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        auto graph_off = [&](const char* where, hipError_t e) {      // never silent: a step that stops replaying is a slower step
+            fprintf(stderr, "[cistaflow] hipGraph replay turned off for this handle: %s: %s\n", where, hipGetErrorString(e));
+            h->err = std::string("hipGraph replay turned off: ") + where + ": " + hipGetErrorString(e);      // cf_last_error (the step itself still succeeds, eagerly)
+            h->graph_on = false;
+        };
+        if (const hipError_t eb = hipStreamBeginCapture(run, hipStreamCaptureModeThreadLocal); eb != hipSuccess) {
             (void)hipGetLastError();
-            h->graph_on = false;               // capture unsupported here: stay eager from now on
+            graph_off("hipStreamBeginCapture", eb);      // capture unsupported here: stay eager from now on
             return step_body(h, a, reuse, st);
         }
         rc = step_body(h, a, reuse, run);
@@ -1960,15 +1965,15 @@ static int step_dispatch(cf_handle* h, const StepArgs& a, bool reuse, hipStream_
         if (rc != CF_OK || ee != hipSuccess || !graph) {
             if (graph) (void)hipGraphDestroy(graph);
             (void)hipGetLastError();
-            h->graph_on = false;
+            graph_off(rc != CF_OK ? "the step failed under capture" : "hipStreamEndCapture", ee);
             if (rc != CF_OK) return rc;
             return step_body(h, a, reuse, st);     // nothing of the failed capture ran: issue the step eagerly
         }
         hipGraphExec_t exec = nullptr;
-        if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess || !exec) {
+        if (const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0); ei != hipSuccess || !exec) {
             (void)hipGraphDestroy(graph);
             (void)hipGetLastError();
-            h->graph_on = false;
+            graph_off("hipGraphInstantiate", ei);
             return step_body(h, a, reuse, st);
         }
         if (h->graphs.size() >= GRAPH_CAP) {      // evict the least recently used executable
