@@ -1644,7 +1644,7 @@ hipError_t launch_conv(const ConvParams& p_in, int batch, hipStream_t s, int til
         else if (tile == 0 && wg16 >= w16min) tile = 47;
         // at most ONE workgroup per CU: the deep-prefetch / software-pipelined instantiation (tile 50, bit-identical), see conv_wino16.hip
         const char* ed = getenv("CF_WINO16_DEEP_MAX");      // read per launch: tests flip it
-        const long deep_max = ed ? atol(ed) : 400;
+        const long deep_max = ed ? atol(ed) : 400;      // (B = 8: convf2 only; convc2 / fh.conv1 at 576 / 768 gain 2-5 % per launch, nothing on the step)
         if (tile == 47 && wg16 <= deep_max) tile = 50;
     }
     // 1x5 / 5x1 layers with transformed weights (the separable GRU): one-dimensional Winograd F(2,5), 1.67x fewer MFMAs (conv_wino1d.hip)
