@@ -324,6 +324,39 @@ def test_persistent_winograd_in_the_model_is_bit_identical(gpu, monkeypatch, win
             assert torch.equal(x, y), t
 
 
+@pytest.mark.parametrize("B", [1, 2])
+def test_deep_winograd16_in_the_model_is_bit_identical(gpu, monkeypatch, B):
+    """conv_wino16_kernel<1> (tile 50: U two chunks ahead, raw ring of four, slot-scheduled chunk step; what launches of at most
+    CF_WINO16_DEEP_MAX workgroups take) computes conv_wino16_kernel<0>'s arithmetic bit for bit: the WHOLE recurrent model at the headline
+    geometry in the small-batch regime, where ~20 launch sites per frame take it, must reproduce the run with it turned off exactly, over
+    enough frames that a counted-vmcnt hand-off race would show (the lesson of tile 49)."""
+    H, W = 180, 240
+    m = build_eiflow(H, W, 5, gpu)
+    evs = [wu.synth_events(B, 5, H, W, 500 + i).to(gpu) for i in range(4)]
+    h = m._be().get(B, gpu)
+    h.plan_enable(True)
+
+    def run(n):
+        prev, st, res = torch.zeros(B, 1, H, W, device=gpu), None, []
+        with torch.no_grad():
+            for t in range(n):
+                I, bf, st = m({"event_voxel": evs[t % 4], "rec_img0": prev}, st, {})
+                prev = I
+                res.append((I.clone(), bf["flow_final"].clone(), st[1].clone(), st[2][0].clone()))
+        torch.cuda.synchronize()
+        return res
+
+    monkeypatch.setenv("CF_WINO16_DEEP_MAX", "0")
+    ref = run(32)
+    monkeypatch.delenv("CF_WINO16_DEEP_MAX", raising=False)
+    got = run(32)
+    kernels = {r["kernel"] for r in h.plan()["rows"]}
+    assert "conv_wino16_kernel<deep>" in kernels and "conv_wino16_kernel" in kernels, kernels      # both instantiations really ran
+    for t, (a, b) in enumerate(zip(ref, got)):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y), t
+
+
 @pytest.mark.parametrize("knob", ["CF_PYRAMID_FUSED"])
 def test_fused_small_launches_are_bit_identical(gpu, monkeypatch, knob):
     """Launch-count reductions on the dependent chains against the launches they replace, same bits:
