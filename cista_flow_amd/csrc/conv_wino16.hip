@@ -340,6 +340,9 @@ __global__ __launch_bounds__(256, DEEP ? 2 : 4) void conv_wino16_kernel(const Co
     // wait, so that this does not rest on the compiler's LDS-DMA bookkeeping in front of the barrier
     wait_vmcnt0();
     __syncthreads();                                // every wave is done with the raw ring before it becomes the exchange buffer
+#ifdef CF_STAMP
+    const long long t_tail_a = __builtin_readcyclecounter();      // MFMA drain + the dead past-the-end loads + barrier
+#endif
     // ---- output transform, j direction (registers): R[0] = M0 + M1 + M2, R[1] = M1 - M2 - M3; C layout: row (tile) 4 kk + r, col t16 ----
     float* X = smem;                                // X[i = wave][bcol][tile 16][cout 32]
 #pragma unroll
@@ -379,13 +382,16 @@ __global__ __launch_bounds__(256, DEEP ? 2 : 4) void conv_wino16_kernel(const Co
         }
     }
     __syncthreads();
+#ifdef CF_STAMP
+    const long long t_tail_b = __builtin_readcyclecounter();      // exchange (three barriers)
+#endif
     const int pp = wave & 1, q0 = (wave >> 1) * 2;  // wave w finishes rows [16 (w >> 1), + 16) of patch w & 1
     patch_tail(p, smem + pp * (32 * EPI_S), b, 0, n0, lane, Ho * Wo, q0, q0 + 2, 1, 0, sMtab + pp * 32);
     if (p.st_partial && wave < 2) patch_stats(p, smem + wave * (32 * EPI_S), b, 0, n0, lane, Ho * Wo, sMtab + wave * 32, reg * 2 + wave, nreg * 2);
 #ifdef CF_STAMP
     if (p.stamp && lane == 0) {      // [DMA wait + barrier, -, -, prologue, chunks, loop, tail, MHz] cycles of this wave
         long long* q = p.stamp + ((long)blockIdx.x * 4 + wave) * 8;
-        q[0] = st_wait; q[1] = 0; q[2] = 0; q[3] = t_loop_begin - t_begin; q[4] = nchunk;
+        q[0] = st_wait; q[1] = t_tail_a - t_loop_end; q[2] = t_tail_b - t_tail_a; q[3] = t_loop_begin - t_begin; q[4] = nchunk;      // [1], [2]: the tail's first two parts
         q[5] = t_loop_end - t_loop_begin; q[6] = __builtin_readcyclecounter() - t_loop_end;
         const long long dr = (long long)__builtin_amdgcn_s_memrealtime() - r_begin;
         q[7] = dr > 0 ? ((__builtin_readcyclecounter() - t_begin) * 100) / dr : 0;

@@ -39,7 +39,11 @@ for case in CASES.split(","):
               " | prologue %6.0f  loop %7.0f  exchange %6.0f cycles | shader clock %4.0f MHz" % (
                   shape[0], r[0], r[1], n, m[2] / n, m[0] / n, m[1] / n, (m[5] - m[0] - m[1] - m[2]) / n, m[3], m[5], m[6], m[7]), flush=True)
         continue
-    if int(tile) == 47:     # conv_wino16_kernel: same slots as tile 46
+    if int(tile) in (47, 50):     # conv_wino16_kernel<0 | 1>: [wait + barrier, tail: drain + dead loads, tail: exchange, prologue, chunks, loop, tail, MHz]
+        print("%-34s tile %2d  %7.1f us %5.1f TF | chunks %3d | per chunk: dma-wait+barrier %4.0f  rest %4.0f | prologue %6.0f  loop %7.0f  tail %6.0f = drain + dead loads + barrier %5.0f, exchange %5.0f, fused epilogue %5.0f cycles | shader clock %4.0f MHz" % (
+                  shape[0], int(tile), r[0], r[1], n, m[0] / n, (m[5] - m[0]) / n, m[3], m[5], m[6], m[1], m[2], m[6] - m[1] - m[2], m[7]), flush=True)
+        continue
+    if int(tile) == 47:     # (old format)
         print("%-34s tile 47  %7.1f us %5.1f TF | chunks %3d | per chunk: dma-wait+barrier %4.0f  issue + reads + transform + 16 mfma(16x16x4) %4.0f"
               " | prologue %6.0f  loop %7.0f  tail %6.0f cycles | shader clock %4.0f MHz" % (
                   shape[0], r[0], r[1], n, m[0] / n, (m[5] - m[0]) / n, m[3], m[5], m[6], m[7]), flush=True)
