@@ -34,7 +34,8 @@ static constexpr int W6_KC = 8;
 static constexpr int W6_PLANE = 128;                        // 16-byte slots per channel-quad plane (100 live)
 static constexpr int W6_RAW = 2 * W6_PLANE * 4;             // floats per raw buffer (4 KB)
 static constexpr int W6_UV = 16 * 64 * 4;                   // floats of a chunk's U block (4096: 16 pos x 32 n x 8 k)
-static constexpr int W6_X = 4 * 2 * 16 * 32;                // floats of the exchange buffer (16 KB)
+static constexpr int W6_XS = 20;                            // exchange row = 16 tiles of one cout, padded to 20 floats: 16-byte accesses of 16 lanes hit 64 different banks
+static constexpr int W6_X = 4 * 2 * 32 * W6_XS;             // floats of the exchange buffer X[i][bcol][cout 32][tile 16 (+4)] (20 KB)
 
 template <int DEEP>
 __global__ __launch_bounds__(256, DEEP ? 2 : 4) void conv_wino16_kernel(const ConvParams p) {
@@ -343,36 +344,55 @@ __global__ __launch_bounds__(256, DEEP ? 2 : 4) void conv_wino16_kernel(const Co
 #ifdef CF_STAMP
     const long long t_tail_a = __builtin_readcyclecounter();      // MFMA drain + the dead past-the-end loads + barrier
 #endif
-    // ---- output transform, j direction (registers): R[0] = M0 + M1 + M2, R[1] = M1 - M2 - M3; C layout: row (tile) 4 kk + r, col t16 ----
-    float* X = smem;                                // X[i = wave][bcol][tile 16][cout 32]
+    // ---- output transform, j direction (registers): R[0] = M0 + M1 + M2, R[1] = M1 - M2 - M3.  C layout of the 16x16x4 MFMA: lane (t16, kk) holds
+    // cout 16 hh + t16 of tiles 4 kk .. 4 kk + 3, i.e. four CONSECUTIVE tiles: X is laid out [i][bcol][cout][tile], so a lane's four values of a
+    // (bcol, hh) are one 16-byte write (r04: was [tile][cout] with sixteen ds_write_b32 and thirty-two ds_read_b32 per lane; at one workgroup
+    // per CU the exchange was 2.35 k of a launch's 25 k cycles) ----
+    float* X = smem;
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh)
+    for (int hh = 0; hh < 2; ++hh) {
+        f32x4 r0, r1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int trow = 4 * kk + r, col = 16 * hh + t16;
-            X[((wave * 2 + 0) * 16 + trow) * 32 + col] = (acc[0][hh][r] + acc[1][hh][r]) + acc[2][hh][r];
-            X[((wave * 2 + 1) * 16 + trow) * 32 + col] = (acc[1][hh][r] - acc[2][hh][r]) - acc[3][hh][r];
+            r0[r] = (acc[0][hh][r] + acc[1][hh][r]) + acc[2][hh][r];
+            r1[r] = (acc[1][hh][r] - acc[2][hh][r]) - acc[3][hh][r];
         }
+        const int col = 16 * hh + t16;
+        *reinterpret_cast<f32x4*>(X + ((wave * 2 + 0) * 32 + col) * W6_XS + 4 * kk) = r0;
+        *reinterpret_cast<f32x4*>(X + ((wave * 2 + 1) * 32 + col) * W6_XS + 4 * kk) = r1;
+    }
     __syncthreads();
-    // ---- i direction across the waves: thread (col = tid & 31) takes patch rows (tid >> 5) + 8 q; patch row = tile * 4 + a * 2 + bb ----
+#ifdef CF_STAMP_FINE
+    const long long t_x1 = __builtin_readcyclecounter();
+#endif
+    // ---- i direction across the waves: thread (col = tid & 31, g = tid >> 5) takes output pixel (a, bb) = ((g >> 1) & 1, g & 1) of the eight
+    // tiles 8 (g >> 2) + q: patch row = tile * 4 + a * 2 + bb; two 16-byte reads per i ----
     float yv[8];
     {
-        const int col = tid & 31;
+        const int col = tid & 31, g = tid >> 5;
+        const int a = (g >> 1) & 1, bb = g & 1, th = g >> 2;
+        f32x4 x[3][2];                                  // rows a, a + 1, a + 2 of the exchange: the three this pixel's row of A^T uses
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float* src = X + (((a + i) * 2 + bb) * 32 + col) * W6_XS + 8 * th;
+            x[i][0] = *reinterpret_cast<const f32x4*>(src);
+            x[i][1] = *reinterpret_cast<const f32x4*>(src + 4);
+        }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const int prow = (tid >> 5) + 8 * q;
-            const int tl = prow >> 2, a = (prow >> 1) & 1, bb = prow & 1;
-            const float x0 = X[((0 * 2 + bb) * 16 + tl) * 32 + col], x1 = X[((1 * 2 + bb) * 16 + tl) * 32 + col];
-            const float x2 = X[((2 * 2 + bb) * 16 + tl) * 32 + col], x3 = X[((3 * 2 + bb) * 16 + tl) * 32 + col];
-            yv[q] = a == 0 ? (x0 + x1) + x2 : (x1 - x2) - x3;
+            const float u0 = x[0][q >> 2][q & 3], u1 = x[1][q >> 2][q & 3], u2 = x[2][q >> 2][q & 3];
+            yv[q] = a == 0 ? (u0 + u1) + u2 : (u0 - u1) - u2;      // (x0 + x1) + x2 | (x1 - x2) - x3
         }
     }
     __syncthreads();                                // everybody has read X: the patches go on top of it
+#ifdef CF_STAMP_FINE
+    const long long t_x2 = __builtin_readcyclecounter();
+#endif
     {
-        const int col = tid & 31;
+        const int col = tid & 31, g = tid >> 5;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const int prow = (tid >> 5) + 8 * q;
+            const int prow = (8 * (g >> 2) + q) * 4 + (g & 3);       // tile * 4 + a * 2 + bb
             smem[(prow >> 5) * (32 * EPI_S) + (prow & 31) * EPI_S + col] = yv[q];
         }
         if (tid < 64) {
@@ -387,11 +407,17 @@ __global__ __launch_bounds__(256, DEEP ? 2 : 4) void conv_wino16_kernel(const Co
 #endif
     const int pp = wave & 1, q0 = (wave >> 1) * 2;  // wave w finishes rows [16 (w >> 1), + 16) of patch w & 1
     patch_tail(p, smem + pp * (32 * EPI_S), b, 0, n0, lane, Ho * Wo, q0, q0 + 2, 1, 0, sMtab + pp * 32);
+    // (r04: the epilogue's bias quad requested in the prologue instead of here took 900 cycles off the tail and put 800 on the prologue -- the
+    // first counted wait then also waits for that cold load, which is older than the first raw patch; not kept)
     if (p.st_partial && wave < 2) patch_stats(p, smem + wave * (32 * EPI_S), b, 0, n0, lane, Ho * Wo, sMtab + wave * 32, reg * 2 + wave, nreg * 2);
 #ifdef CF_STAMP
     if (p.stamp && lane == 0) {      // [DMA wait + barrier, -, -, prologue, chunks, loop, tail, MHz] cycles of this wave
         long long* q = p.stamp + ((long)blockIdx.x * 4 + wave) * 8;
+#ifdef CF_STAMP_FINE
+        q[0] = t_x1 - t_tail_a; q[1] = t_x2 - t_x1; q[2] = t_tail_b - t_x2; q[3] = t_loop_begin - t_begin; q[4] = nchunk;      // the exchange in three parts
+#else
         q[0] = st_wait; q[1] = t_tail_a - t_loop_end; q[2] = t_tail_b - t_tail_a; q[3] = t_loop_begin - t_begin; q[4] = nchunk;      // [1], [2]: the tail's first two parts
+#endif
         q[5] = t_loop_end - t_loop_begin; q[6] = __builtin_readcyclecounter() - t_loop_end;
         const long long dr = (long long)__builtin_amdgcn_s_memrealtime() - r_begin;
         q[7] = dr > 0 ? ((__builtin_readcyclecounter() - t_begin) * 100) / dr : 0;
